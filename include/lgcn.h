@@ -1,0 +1,218 @@
+/*
+ * lgcn.h -- C ABI of the MI355X (gfx950) LaneGCN graph-convolution hot path.
+ *
+ * This is the drop-in boundary for the path SURVEY.md section 8 scopes:
+ * graph_gather -> MapNet (4 x LaneConv) -> A2M -> M2M -> M2A -> A2A of the
+ * reference's lanegcn.py.  The reference has no FFI of its own (it is 100 %
+ * Python on ATen); each entry point below names the reference lines whose
+ * arithmetic it replaces.  The host side (lanegcn-1_amd/, Python) mirrors the
+ * reference's nn.Module interface and reaches these symbols through ctypes.
+ *
+ * Conventions (all entry points):
+ *   - extern "C", returns int: 0 = OK, <0 = LGCN_E* (bad argument, nothing
+ *     launched), >0 = hipError_t of the failed launch.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *     the caller owns all memory including workspaces; nothing is allocated,
+ *     no global state, no implicit synchronisation, re-entrant.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *   - feature tensors are row-major fp32 with C = 128 channels (LGCN_C);
+ *     indices are int32 inside the library; int64 is accepted/produced at the
+ *     edges where the reference's tensors are int64 (utils.py:88-96 to_long).
+ *   - kernels are atomic-free on floating point data: results are bitwise
+ *     repeatable run to run.
+ */
+#ifndef LGCN_H
+#define LGCN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LGCN_VERSION 100       /* 0.1.0 */
+#define LGCN_C 128             /* n_map = n_actor = 128 (lanegcn.py:78-79) */
+#define LGCN_TM 32             /* rows of one MFMA tile / CSR tile */
+#define LGCN_MAX_REL 16        /* ctr + 14 lane relations (+1 spare) */
+
+enum {
+    LGCN_OK = 0,
+    LGCN_EINVAL = -1,          /* null pointer / negative size / bad flag */
+    LGCN_ESHAPE = -2,          /* size not supported by the kernels */
+    LGCN_EALIGN = -3           /* pointer not 16-byte aligned */
+};
+
+int lgcn_version(void);
+const char *lgcn_strerror(int code);
+
+/* ------------------------------------------------------------------ */
+/* Integer path (bit-exact against the reference)                      */
+/* ------------------------------------------------------------------ */
+
+/*
+ * graph_gather index offsetting, lanegcn.py:191-208:
+ *   out[e] = in[e] + base[seg(e)],  seg(e) = the segment with
+ *   seg_off[seg] <= e < seg_off[seg+1].
+ * One call handles every (relation, u|v, scene) segment of a batch at once:
+ * `in` is the concatenation of the per-scene local index arrays, `base` the
+ * node offset of the scene each segment belongs to (counts[j], :175-182).
+ * out64 and/or out32 may be NULL.
+ */
+int lgcn_graph_gather(const int64_t *in, int64_t n_elem,
+                      const int64_t *seg_off, const int64_t *seg_base, int n_seg,
+                      int64_t *out64, int32_t *out32, void *stream);
+
+/*
+ * Lane-graph plan: COO (u = destination, v = source) of n_rel relations
+ * -> tile-major CSR by destination.  Replaces the 14 index_add_ scatter
+ * patterns of lanegcn.py:333-354 / 450-471 by an atomic-free gather.
+ *
+ *   key(n, r)   = ((n / 32) * n_rel + r) * 32 + n % 32
+ *   rowptr      : [n_tiles * n_rel * 32 + 1] int32, n_tiles = ceil(n_nodes/32)
+ *   col         : [sum_r n_edges[r]] int32, sources of row key in ascending
+ *                 order of v (duplicates kept: index_add_ adds them twice)
+ *
+ * u/v of relation r are read from u[r], v[r] (host arrays of device
+ * pointers to int64 tensors).  ws: int32 workspace of
+ * lgcn_csr_ws_elems(n_nodes, n_rel) elements.
+ */
+int64_t lgcn_csr_rowptr_elems(int64_t n_nodes, int n_rel);
+int64_t lgcn_csr_ws_elems(int64_t n_nodes, int n_rel);
+int lgcn_csr_build(const int64_t *const *u_host, const int64_t *const *v_host,
+                   const int64_t *n_edges_host, int n_rel, int64_t n_nodes,
+                   int32_t *rowptr, int32_t *col, int32_t *ws, void *stream);
+
+/*
+ * Att pair search, lanegcn.py:672-689.  For every scene i and every
+ * (t, s) in agt_i x ctx_i:  sqrt(fl(dx*dx) + fl(dy*dy)) <= dist_th  in fp32
+ * without FMA contraction, pairs emitted in row-major (t, s) order, scenes
+ * concatenated.  legacy_offsets != 0 reproduces the reference quirk that a
+ * scene with zero pairs does not advance hi_count / wi_count (:681-687).
+ *
+ *   agt_ctrs [T,2], ctx_ctrs [S,2] fp32: concatenated per-scene centres
+ *   agt_off [B+1], ctx_off [B+1] int32: scene offsets into them
+ *   hi, wi   : [cap] int32 outputs (cap >= sum_i t_i * s_i is always enough)
+ *   n_pairs  : [1] int32 output (device): P
+ *   rowptr   : [T+1] int32 output: rowptr[h] = first pair with hi >= h, i.e.
+ *              the segments index_add_(0, hi, .) (:703) reduces over
+ *   ws       : int32 workspace, lgcn_pairs_ws_elems(T, B) elements
+ * If P would exceed cap the pairs beyond cap are dropped and *n_pairs = -P.
+ */
+int64_t lgcn_pairs_ws_elems(int64_t n_agt, int n_scenes);
+int lgcn_pairs_build(const float *agt_ctrs, const int32_t *agt_off,
+                     const float *ctx_ctrs, const int32_t *ctx_off,
+                     int n_scenes, int64_t n_agt, int64_t n_ctx,
+                     float dist_th, int legacy_offsets,
+                     int32_t *hi, int32_t *wi, int64_t cap,
+                     int32_t *n_pairs, int32_t *rowptr, int32_t *ws,
+                     void *stream);
+
+/* int32 -> int64 widening of the first *n (device count, clamped to cap)
+ * entries; the tail is left untouched.  Used to hand hi/wi back as the
+ * reference's LongTensors. */
+int lgcn_widen_i32(const int32_t *in, const int32_t *n_dev, int64_t cap,
+                   int64_t *out, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* Floating point path (fp32, f32-input MFMA; tolerance 1e-4 on features) */
+/* ------------------------------------------------------------------ */
+
+/*
+ * Weight prepacking.  W is an nn.Linear weight [128, k_real] with row stride
+ * ld (floats); the packed image feeds v_mfma_f32_32x32x2_f32 with one 16-byte
+ * load per lane and 8 k-steps:
+ *   out[w][q][lane][j] = W[32*w + (lane & 31)][8*q + 4*(lane >> 5) + j]
+ * for w < 4, q < k_pad/8, j < 4 (zero for k >= k_real).  k_pad % 8 == 0.
+ * out holds 128 * k_pad floats.
+ */
+int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad,
+                     float *out, void *stream);
+
+/* One relation of an aggregate-GEMM stage (see lgcn_agg_mlp). */
+typedef struct {
+    const float *src;        /* [*,128] source rows                        */
+    const float *wp;         /* packed weight, k_pad = 128                 */
+    int32_t mode;            /* LGCN_REL_*                                 */
+    int32_t ridx;            /* LGCN_REL_CSR: relation index in the plan   */
+} lgcn_rel_t;
+
+enum {
+    LGCN_REL_IDENT = 0,      /* A[n] = src[n]                              */
+    LGCN_REL_CSR = 1,        /* A[n] = sum_{e in row key(n,ridx)} src[col[e]] */
+    LGCN_REL_RANGE = 2       /* A[n] = sum_{p in [rowptr[n],rowptr[n+1])} src[p] */
+};
+
+enum {                        /* lgcn_agg_mlp flags                         */
+    LGCN_F_GN1 = 1, LGCN_F_RELU1 = 2, LGCN_F_GEMM2 = 4, LGCN_F_GN2 = 8,
+    LGCN_F_RES = 16, LGCN_F_RELU2 = 32
+};
+
+typedef struct {
+    int64_t n_rows;          /* N destination rows                         */
+    int32_t n_rel;           /* 1..LGCN_MAX_REL                            */
+    int32_t n_rel_csr;       /* relations in the CSR plan (rowptr layout)  */
+    int32_t flags;           /* LGCN_F_*                                   */
+    float eps;               /* GroupNorm eps (1e-5)                       */
+    lgcn_rel_t rel[LGCN_MAX_REL];
+    const int32_t *rowptr;   /* CSR plan rowptr, or [N+1] for RANGE        */
+    const int32_t *col;      /* CSR plan col                               */
+    const float *x4_a;       /* optional [N,2] extra inputs (A2M meta:     */
+    const float *x4_b;       /*   turn[N,2], control[N], intersect[N])     */
+    const float *x4_c;
+    const float *w4;         /* [128,4] weight columns for them, or NULL   */
+    const float *gn1_g, *gn1_b;
+    const float *wp2;        /* packed stage-2 weight                      */
+    const float *gn2_g, *gn2_b;
+    const float *res;        /* [N,128] residual                           */
+    float *out;              /* [N,128]                                    */
+    float *out_pre;          /* optional [N,128]: stage-1 pre-GN1 sums     */
+} lgcn_agg_mlp_t;
+
+/*
+ * Fused "aggregate -> GEMM -> GN -> ReLU -> GEMM -> GN -> +res -> ReLU" row
+ * block.  With the 15 relations ctr, pre0, suc0, ..., left, right it is one
+ * LaneConv layer (lanegcn.py:331-362 == 448-479):
+ *   T = sum_r (sum_{e:u=n} X[v]) W_r^T ; Y = ReLU(GN1(T)) ;
+ *   out = ReLU(GN2(Y W2^T) + res)
+ * With {IDENT(a, W_agt), RANGE(m, W_c1)} it is the tail of Att.forward
+ * (:702-709); with one IDENT relation and subsets of the flags it is
+ * layers.Linear (layers.py:65-87), Att.query (:696), A2M.meta (:387-395).
+ */
+int lgcn_agg_mlp(const lgcn_agg_mlp_t *p_host, void *stream);
+
+/*
+ * MapNet input stage, lanegcn.py:324-327:
+ *   out = ReLU( GN_a(W_a2 ReLU(W_a1 ctr + b_a1)) + GN_s(W_s2 ReLU(W_s1 seg + b_s1)) )
+ * ctrs, feats: [N,2]; w1: [128,2] + b1 [128] (nn.Linear(2,128)); wp2: packed.
+ */
+int lgcn_mapnet_input(const float *ctrs, const float *feats, int64_t n_rows,
+                      const float *wa1, const float *ba1, const float *wpa2,
+                      const float *ga, const float *bta,
+                      const float *ws1, const float *bs1, const float *wps2,
+                      const float *gs, const float *bts,
+                      float eps, float *out, void *stream);
+
+/*
+ * Att.forward per-pair MLP, lanegcn.py:691-700, for pairs p < *n_pairs:
+ *   d   = agt_ctrs[hi[p]] - ctx_ctrs[wi[p]]
+ *   e   = ReLU(GN_d(W_d2 ReLU(W_d0 d + b_d0)))
+ *   m_p = ReLU(GN_c( W_c0[:, 0:128] e + U[hi[p]] + V[wi[p]] ))
+ * where U = query(agts) W_c0[:,128:256]^T (per target row) and
+ * V = ctx W_c0[:,256:384]^T (per context row) were hoisted out of the pair
+ * loop (row-wise Linear commutes with the gather).  ctx.1 (:654) is applied
+ * after the segment sum by lgcn_agg_mlp (it is linear).
+ * m: [cap,128] output rows.
+ */
+int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs,
+                   const int32_t *hi, const int32_t *wi,
+                   const int32_t *n_pairs, int64_t cap,
+                   const float *wd0, const float *bd0, const float *wpd2,
+                   const float *gd, const float *btd,
+                   const float *wpc0e, const float *U, const float *V,
+                   const float *gc, const float *btc,
+                   float eps, float *m, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGCN_H */

@@ -1,0 +1,79 @@
+"""ctypes binding of liblgcn.so (C ABI: include/lgcn.h).  Fails loudly when the library is absent."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblgcn.so")
+
+MAX_REL = 16
+REL_IDENT, REL_CSR, REL_RANGE = 0, 1, 2
+F_GN1, F_RELU1, F_GEMM2, F_GN2, F_RES, F_RELU2 = 1, 2, 4, 8, 16, 32
+
+
+class LgcnError(RuntimeError):
+    pass
+
+
+class Rel(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("wp", C.c_void_p), ("mode", C.c_int32), ("ridx", C.c_int32)]
+
+
+class AggMlp(C.Structure):
+    _fields_ = [
+        ("n_rows", C.c_int64), ("n_rel", C.c_int32), ("n_rel_csr", C.c_int32),
+        ("flags", C.c_int32), ("eps", C.c_float),
+        ("rel", Rel * MAX_REL),
+        ("rowptr", C.c_void_p), ("col", C.c_void_p),
+        ("x4_a", C.c_void_p), ("x4_b", C.c_void_p), ("x4_c", C.c_void_p), ("w4", C.c_void_p),
+        ("gn1_g", C.c_void_p), ("gn1_b", C.c_void_p),
+        ("wp2", C.c_void_p), ("gn2_g", C.c_void_p), ("gn2_b", C.c_void_p),
+        ("res", C.c_void_p), ("out", C.c_void_p), ("out_pre", C.c_void_p),
+    ]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/lgcn.h declares
+SIGNATURES = {
+    "lgcn_version": (C.c_int, []),
+    "lgcn_strerror": (C.c_char_p, [_I]),
+    "lgcn_graph_gather": (C.c_int, [_P, _L, _P, _P, _I, _P, _P, _P]),
+    "lgcn_csr_rowptr_elems": (C.c_int64, [_L, _I]),
+    "lgcn_csr_ws_elems": (C.c_int64, [_L, _I]),
+    "lgcn_csr_build": (C.c_int, [_P, _P, _P, _I, _L, _P, _P, _P, _P]),
+    "lgcn_pairs_ws_elems": (C.c_int64, [_L, _I]),
+    "lgcn_pairs_build": (C.c_int, [_P, _P, _P, _P, _I, _L, _L, _F, _I, _P, _P, _L, _P, _P, _P, _P]),
+    "lgcn_widen_i32": (C.c_int, [_P, _P, _L, _P, _P]),
+    "lgcn_pack_weight": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "lgcn_agg_mlp": (C.c_int, [C.POINTER(AggMlp), _P]),
+    "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _P, _P]),
+    "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _P, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load liblgcn.so once; raise LgcnError with build instructions if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LgcnError(
+            "liblgcn.so not found at %s -- the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+            "`make -C lanegcn-1_amd/csrc`." % LIB_PATH
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().lgcn_strerror(int(rc)).decode()
+        raise LgcnError("%s failed: %s (code %d)" % (what, msg, rc))

@@ -1,0 +1,35 @@
+// Shared device/host helpers for the LaneGCN hot-path kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "lgcn.h"
+
+namespace lgcn {
+
+constexpr int kC = LGCN_C;          // channels
+constexpr int kTM = LGCN_TM;        // rows per tile
+constexpr int kLDA = kC + 4;        // padded LDS row stride (floats): 528 B rows,
+                                    // conflict-free for ds_read_b128 over 16 rows
+constexpr int kWave = 64;
+
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+#define LGCN_CHECK_PTR(p) do { if ((p) == nullptr) return LGCN_EINVAL; } while (0)
+#define LGCN_CHECK_ALIGN16(p) do { if ((reinterpret_cast<uintptr_t>(p) & 15u) != 0) return LGCN_EALIGN; } while (0)
+
+inline int launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? LGCN_OK : static_cast<int>(e);
+}
+
+// Blocks b and b+8 share an XCD (round-robin dispatch); give every XCD one
+// contiguous chunk of tiles so that neighbouring tiles (same scene, shared
+// gather rows) hit the same L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_chunk_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = bid & 7, k = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+}  // namespace lgcn

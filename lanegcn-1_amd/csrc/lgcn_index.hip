@@ -1,0 +1,424 @@
+// Integer path of the LaneGCN hot path: graph_gather offsets, tile-major CSR
+// plan, distance-gated pair search.  Everything here is bit-exact against the
+// reference (lanegcn.py:171-209, 672-689); this file is compiled with
+// -ffp-contract=off so the pair-search distance is evaluated exactly like
+// ATen's sub / pow(2) / sum / sqrt / le chain (no FMA).
+#include "lgcn_common.hpp"
+
+namespace lgcn {
+
+// ---------------------------------------------------------------- scan ----
+// Exclusive scan of int32, three launches: per-block scan + block totals,
+// scan of the totals (single block, looping), add-back.
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+// Block-wide exclusive scan of one value per thread; returns the exclusive
+// prefix, *total = block sum.  NT threads (multiple of 64, <= 1024).
+template <int NT>
+__device__ __forceinline__ int block_exclusive_scan(int v, int *total, int *lds /*[NT/64 + 1]*/) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int inc = wave_inclusive_scan(v, lane);
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < NT / 64; ++i) { int t = lds[i]; lds[i] = run; run += t; }
+        lds[NT / 64] = run;
+    }
+    __syncthreads();
+    const int base = lds[w];
+    *total = lds[NT / 64];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_blocks(const int32_t *in, int32_t *out,
+                                                              int32_t *sums, int64_t n) {
+    __shared__ int lds[kScanThreads / 64 + 1];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+    int v[kScanItems];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        v[i] = (base + i < n) ? in[base + i] : 0;
+        s += v[i];
+    }
+    int total;
+    int pre = block_exclusive_scan<kScanThreads>(s, &total, lds);
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i) {
+        if (base + i < n) out[base + i] = pre;
+        pre += v[i];
+    }
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_sums(int32_t *sums, int nb) {
+    __shared__ int lds[1024 / 64 + 1];
+    int carry = 0;
+    for (int c = 0; c < nb; c += 1024) {
+        const int i = c + threadIdx.x;
+        const int v = i < nb ? sums[i] : 0;
+        int total;
+        const int pre = block_exclusive_scan<1024>(v, &total, lds);
+        if (i < nb) sums[i] = pre + carry;
+        carry += total;
+    }
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_add(int32_t *out, const int32_t *sums, int64_t n) {
+    const int add = sums[blockIdx.x];
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i)
+        if (base + i < n) out[base + i] += add;
+}
+
+inline int64_t scan_ws_elems(int64_t n) { return (n + kScanTile - 1) / kScanTile + 1; }
+
+// out may alias in.
+static int exclusive_scan(const int32_t *in, int32_t *out, int64_t n, int32_t *sums, hipStream_t st) {
+    if (n <= 0) return LGCN_OK;
+    const int64_t nb = (n + kScanTile - 1) / kScanTile;
+    if (nb > 0x7fffffff) return LGCN_ESHAPE;
+    hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, out, sums, n);
+    if (nb > 1) {
+        hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, sums, (int)nb);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(kScanThreads), 0, st, out, sums, n);
+    }
+    return launch_status();
+}
+
+// -------------------------------------------------------- graph_gather ----
+__global__ __launch_bounds__(256) void k_graph_gather(const int64_t *in, int64_t n,
+                                                      const int64_t *seg_off, const int64_t *seg_base,
+                                                      int n_seg, int64_t *out64, int32_t *out32) {
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        // last segment with seg_off[s] <= e (empty segments are skipped by
+        // taking the LAST one: seg_off is non-decreasing)
+        int lo = 0, hi = n_seg;  // invariant: seg_off[lo] <= e < seg_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_off[mid] <= e) lo = mid; else hi = mid;
+        }
+        const int64_t v = in[e] + seg_base[lo];
+        if (out64) out64[e] = v;
+        if (out32) out32[e] = (int32_t)v;
+    }
+}
+
+// ----------------------------------------------------------- CSR plan -----
+struct CooTable {
+    const int64_t *u[LGCN_MAX_REL];
+    const int64_t *v[LGCN_MAX_REL];
+    int64_t start[LGCN_MAX_REL + 1];  // prefix of n_edges
+    int n_rel;
+    int64_t n_nodes;
+};
+
+__device__ __forceinline__ int64_t csr_key(int64_t n, int r, int n_rel) {
+    return ((n >> 5) * n_rel + r) * 32 + (n & 31);
+}
+
+// pass 0: count, pass 1: fill
+template <int PASS>
+__global__ __launch_bounds__(256) void k_csr_edges(const CooTable t, int32_t *cnt_or_cursor,
+                                                   const int32_t *rowptr, int32_t *col) {
+    const int64_t total = t.start[t.n_rel];
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        int r = 0;
+        while (r + 1 < t.n_rel && e >= t.start[r + 1]) ++r;
+        const int64_t le = e - t.start[r];
+        const int64_t u = t.u[r][le], v = t.v[r][le];
+        if (u < 0 || u >= t.n_nodes || v < 0 || v >= t.n_nodes) continue;  // never index out of bounds
+        const int64_t k = csr_key(u, r, t.n_rel);
+        if (PASS == 0) {
+            atomicAdd(&cnt_or_cursor[k], 1);
+        } else {
+            const int pos = rowptr[k] + atomicAdd(&cnt_or_cursor[k], 1);
+            col[pos] = (int32_t)v;
+        }
+    }
+}
+
+// Canonical order inside each row (ascending source index) so that the
+// floating-point gather-sum that consumes the plan is deterministic.
+__global__ __launch_bounds__(256) void k_csr_sort_rows(const int32_t *rowptr, int32_t *col, int64_t n_keys) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_keys) return;
+    const int b = rowptr[k], e = rowptr[k + 1];
+    for (int i = b + 1; i < e; ++i) {
+        const int x = col[i];
+        int j = i - 1;
+        while (j >= b && col[j] > x) { col[j + 1] = col[j]; --j; }
+        col[j + 1] = x;
+    }
+}
+
+// -------------------------------------------------------- pair search -----
+__device__ __forceinline__ int find_scene(const int32_t *off, int n_scenes, int g) {
+    int lo = 0, hi = n_scenes;  // off[lo] <= g < off[hi]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// lanegcn.py:676-678: dist = a - c; sqrt((dist ** 2).sum(2)) <= th, fp32, no FMA.
+__device__ __forceinline__ bool within(float ax, float ay, float cx, float cy, float th) {
+    const float dx = __fsub_rn(ax, cx), dy = __fsub_rn(ay, cy);
+    const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+    return __fsqrt_rn(d2) <= th;
+}
+
+// One wave per target row.  PASS 0 counts, PASS 1 writes (hi, wi).
+template <int PASS>
+__global__ __launch_bounds__(256) void k_pairs_rows(const float2 *agt, const int32_t *agt_off,
+                                                    const float2 *ctx, const int32_t *ctx_off,
+                                                    int n_scenes, int n_agt, float th,
+                                                    int32_t *rowcnt, const int32_t *rowptr,
+                                                    const int32_t *hi_base, const int32_t *wi_base,
+                                                    int32_t *hi, int32_t *wi, int64_t cap) {
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (g >= n_agt) return;
+    const int sc = find_scene(agt_off, n_scenes, g);
+    const int c0 = ctx_off[sc], c1 = ctx_off[sc + 1];
+    const float2 a = agt[g];
+    int count = 0;
+    int64_t pos = 0;
+    int hval = 0, wbase = 0;
+    if (PASS == 1) {
+        pos = rowptr[g];
+        hval = g - agt_off[sc] + hi_base[sc];
+        wbase = wi_base[sc] - c0;
+    }
+    for (int s0 = c0; s0 < c1; s0 += 64) {
+        const int s = s0 + lane;
+        bool ok = false;
+        if (s < c1) {
+            const float2 c = ctx[s];
+            ok = within(a.x, a.y, c.x, c.y, th);
+        }
+        const unsigned long long m = __ballot(ok);
+        if (PASS == 0) {
+            count += __popcll(m);
+        } else {
+            if (ok) {
+                const int64_t o = pos + __popcll(m & ((1ull << lane) - 1ull));
+                if (o < cap) { hi[o] = hval; wi[o] = s + wbase; }
+            }
+            pos += __popcll(m);
+        }
+    }
+    if (PASS == 0 && lane == 0) rowcnt[g] = count;
+}
+
+// Per-scene index bases (lanegcn.py:681-687).  legacy: a scene without pairs
+// does not advance the running counts.  Also publishes P.
+__global__ __launch_bounds__(1024) void k_pairs_bases(const int32_t *rowptr, const int32_t *agt_off,
+                                                      const int32_t *ctx_off, int n_scenes, int n_agt,
+                                                      int legacy, int64_t cap, int32_t *hi_base,
+                                                      int32_t *wi_base, int32_t *n_pairs) {
+    __shared__ int lds[1024 / 64 + 1];
+    int carry_h = 0, carry_w = 0;
+    for (int c = 0; c < n_scenes; c += 1024) {
+        const int i = c + threadIdx.x;
+        int th = 0, tw = 0;
+        if (i < n_scenes) {
+            const int a0 = agt_off[i], a1 = agt_off[i + 1];
+            const bool nonempty = rowptr[a1] - rowptr[a0] > 0;
+            if (!legacy || nonempty) { th = a1 - a0; tw = ctx_off[i + 1] - ctx_off[i]; }
+        }
+        int tot_h, tot_w;
+        const int ph = block_exclusive_scan<1024>(th, &tot_h, lds);
+        const int pw = block_exclusive_scan<1024>(tw, &tot_w, lds);
+        if (i < n_scenes) { hi_base[i] = ph + carry_h; wi_base[i] = pw + carry_w; }
+        carry_h += tot_h;
+        carry_w += tot_w;
+    }
+    if (threadIdx.x == 0) {
+        const int P = rowptr[n_agt];
+        *n_pairs = (int64_t)P > cap ? -P : P;
+    }
+}
+
+// rowptr_q[h] = first p with hi[p] >= h (hi is non-decreasing).
+__global__ __launch_bounds__(256) void k_pairs_rowptr(const int32_t *hi, const int32_t *n_pairs,
+                                                      int64_t cap, int n_agt, int32_t *rowptr_q) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h > n_agt) return;
+    int P = *n_pairs;
+    if (P < 0) P = (int)cap;
+    int lo = 0, hi_ = P;  // answer in [lo, hi_]
+    while (lo < hi_) {
+        const int mid = (lo + hi_) >> 1;
+        if (hi[mid] >= h) hi_ = mid; else lo = mid + 1;
+    }
+    rowptr_q[h] = lo;
+}
+
+__global__ __launch_bounds__(256) void k_widen(const int32_t *in, const int32_t *n_dev, int64_t cap, int64_t *out) {
+    int64_t n = *n_dev;
+    if (n < 0 || n > cap) n = cap;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i];
+}
+
+static inline unsigned grid_for(int64_t n, int threads, int64_t max_blocks = 4096) {
+    int64_t b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (unsigned)b;
+}
+
+}  // namespace lgcn
+
+using namespace lgcn;
+
+extern "C" {
+
+int lgcn_version(void) { return LGCN_VERSION; }
+
+const char *lgcn_strerror(int code) {
+    switch (code) {
+        case LGCN_OK: return "ok";
+        case LGCN_EINVAL: return "invalid argument (null pointer, negative size or bad flag)";
+        case LGCN_ESHAPE: return "unsupported shape";
+        case LGCN_EALIGN: return "pointer not 16-byte aligned";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown lgcn error";
+    }
+}
+
+int lgcn_graph_gather(const int64_t *in, int64_t n_elem, const int64_t *seg_off, const int64_t *seg_base,
+                      int n_seg, int64_t *out64, int32_t *out32, void *stream) {
+    if (n_elem < 0 || n_seg < 0) return LGCN_EINVAL;
+    if (n_elem == 0) return LGCN_OK;
+    LGCN_CHECK_PTR(in); LGCN_CHECK_PTR(seg_off); LGCN_CHECK_PTR(seg_base);
+    if (n_seg < 1 || (!out64 && !out32)) return LGCN_EINVAL;
+    hipLaunchKernelGGL(k_graph_gather, dim3(grid_for(n_elem, 256)), dim3(256), 0, (hipStream_t)stream,
+                       in, n_elem, seg_off, seg_base, n_seg, out64, out32);
+    return launch_status();
+}
+
+int64_t lgcn_csr_rowptr_elems(int64_t n_nodes, int n_rel) {
+    if (n_nodes < 0 || n_rel < 1 || n_rel > LGCN_MAX_REL) return LGCN_EINVAL;
+    return ((n_nodes + 31) / 32) * n_rel * 32 + 1;
+}
+
+int64_t lgcn_csr_ws_elems(int64_t n_nodes, int n_rel) {
+    const int64_t k = lgcn_csr_rowptr_elems(n_nodes, n_rel);
+    if (k < 0) return k;
+    return k + scan_ws_elems(k);  // cursor + scan block sums
+}
+
+int lgcn_csr_build(const int64_t *const *u_host, const int64_t *const *v_host, const int64_t *n_edges_host,
+                   int n_rel, int64_t n_nodes, int32_t *rowptr, int32_t *col, int32_t *ws, void *stream) {
+    if (n_rel < 1 || n_rel > LGCN_MAX_REL || n_nodes < 0) return LGCN_EINVAL;
+    LGCN_CHECK_PTR(u_host); LGCN_CHECK_PTR(v_host); LGCN_CHECK_PTR(n_edges_host);
+    LGCN_CHECK_PTR(rowptr); LGCN_CHECK_PTR(ws);
+    hipStream_t st = (hipStream_t)stream;
+    CooTable t;
+    t.n_rel = n_rel;
+    t.n_nodes = n_nodes;
+    t.start[0] = 0;
+    for (int r = 0; r < n_rel; ++r) {
+        if (n_edges_host[r] < 0) return LGCN_EINVAL;
+        if (n_edges_host[r] > 0 && (!u_host[r] || !v_host[r])) return LGCN_EINVAL;
+        t.u[r] = u_host[r];
+        t.v[r] = v_host[r];
+        t.start[r + 1] = t.start[r] + n_edges_host[r];
+    }
+    for (int r = n_rel; r < LGCN_MAX_REL; ++r) { t.u[r] = nullptr; t.v[r] = nullptr; t.start[r + 1] = t.start[n_rel]; }
+    const int64_t total = t.start[n_rel];
+    if (total > 0x7fffffff || n_nodes > 0x7fffffff) return LGCN_ESHAPE;
+    if (total > 0) LGCN_CHECK_PTR(col);
+    const int64_t nk1 = lgcn_csr_rowptr_elems(n_nodes, n_rel);  // keys + 1
+    int32_t *cursor = ws;
+    int32_t *sums = ws + nk1;
+    hipError_t e = hipMemsetAsync(rowptr, 0, nk1 * sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(cursor, 0, nk1 * sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    if (total > 0) {
+        hipLaunchKernelGGL((k_csr_edges<0>), dim3(grid_for(total, 256)), dim3(256), 0, st, t, rowptr, nullptr, nullptr);
+    }
+    int rc = exclusive_scan(rowptr, rowptr, nk1, sums, st);
+    if (rc != LGCN_OK) return rc;
+    if (total > 0) {
+        hipLaunchKernelGGL((k_csr_edges<1>), dim3(grid_for(total, 256)), dim3(256), 0, st, t, cursor, rowptr, col);
+        hipLaunchKernelGGL(k_csr_sort_rows, dim3((unsigned)((nk1 - 1 + 255) / 256)), dim3(256), 0, st,
+                           rowptr, col, nk1 - 1);
+    }
+    return launch_status();
+}
+
+int64_t lgcn_pairs_ws_elems(int64_t n_agt, int n_scenes) {
+    if (n_agt < 0 || n_scenes < 0) return LGCN_EINVAL;
+    // rowptr_true [T+1] + scan sums + hi_base [B] + wi_base [B]
+    return (n_agt + 1) + scan_ws_elems(n_agt + 1) + 2 * (int64_t)n_scenes;
+}
+
+int lgcn_pairs_build(const float *agt_ctrs, const int32_t *agt_off, const float *ctx_ctrs,
+                     const int32_t *ctx_off, int n_scenes, int64_t n_agt, int64_t n_ctx, float dist_th,
+                     int legacy_offsets, int32_t *hi, int32_t *wi, int64_t cap, int32_t *n_pairs,
+                     int32_t *rowptr, int32_t *ws, void *stream) {
+    if (n_scenes < 1 || n_agt < 0 || n_ctx < 0 || cap < 0) return LGCN_EINVAL;
+    if (n_agt > 0x7ffffff0 || n_ctx > 0x7ffffff0 || cap > 0x7ffffff0) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(agt_off); LGCN_CHECK_PTR(ctx_off); LGCN_CHECK_PTR(n_pairs);
+    LGCN_CHECK_PTR(rowptr); LGCN_CHECK_PTR(ws);
+    if (n_agt > 0) LGCN_CHECK_PTR(agt_ctrs);
+    if (n_ctx > 0) LGCN_CHECK_PTR(ctx_ctrs);
+    if (cap > 0) { LGCN_CHECK_PTR(hi); LGCN_CHECK_PTR(wi); }
+    hipStream_t st = (hipStream_t)stream;
+    const int T = (int)n_agt;
+    int32_t *rp_true = ws;
+    int32_t *sums = rp_true + (T + 1);
+    int32_t *hi_base = sums + scan_ws_elems(T + 1);
+    int32_t *wi_base = hi_base + n_scenes;
+    // rowcnt[T] = 0 so that the exclusive scan over T+1 entries yields P at [T]
+    hipError_t e = hipMemsetAsync(rp_true + T, 0, sizeof(int32_t), st);
+    if (e != hipSuccess) return (int)e;
+    const unsigned row_blocks = (unsigned)((T + 3) / 4);
+    if (T > 0) {
+        hipLaunchKernelGGL((k_pairs_rows<0>), dim3(row_blocks), dim3(256), 0, st,
+                           (const float2 *)agt_ctrs, agt_off, (const float2 *)ctx_ctrs, ctx_off, n_scenes, T,
+                           dist_th, rp_true, nullptr, nullptr, nullptr, nullptr, nullptr, (int64_t)0);
+    }
+    int rc = exclusive_scan(rp_true, rp_true, (int64_t)T + 1, sums, st);
+    if (rc != LGCN_OK) return rc;
+    hipLaunchKernelGGL(k_pairs_bases, dim3(1), dim3(1024), 0, st, rp_true, agt_off, ctx_off, n_scenes, T,
+                       legacy_offsets, cap, hi_base, wi_base, n_pairs);
+    if (T > 0) {
+        hipLaunchKernelGGL((k_pairs_rows<1>), dim3(row_blocks), dim3(256), 0, st,
+                           (const float2 *)agt_ctrs, agt_off, (const float2 *)ctx_ctrs, ctx_off, n_scenes, T,
+                           dist_th, nullptr, rp_true, hi_base, wi_base, hi, wi, cap);
+    }
+    hipLaunchKernelGGL(k_pairs_rowptr, dim3((unsigned)((T + 1 + 255) / 256)), dim3(256), 0, st,
+                       hi, n_pairs, cap, T, rowptr);
+    return launch_status();
+}
+
+int lgcn_widen_i32(const int32_t *in, const int32_t *n_dev, int64_t cap, int64_t *out, void *stream) {
+    if (cap < 0) return LGCN_EINVAL;
+    if (cap == 0) return LGCN_OK;
+    LGCN_CHECK_PTR(in); LGCN_CHECK_PTR(n_dev); LGCN_CHECK_PTR(out);
+    hipLaunchKernelGGL(k_widen, dim3(grid_for(cap, 256, 1024)), dim3(256), 0, (hipStream_t)stream, in, n_dev, cap, out);
+    return launch_status();
+}
+
+}  // extern "C"

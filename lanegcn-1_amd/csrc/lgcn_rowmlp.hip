@@ -1,0 +1,514 @@
+// Floating-point path of the LaneGCN hot path on gfx950 (MI355X):
+// fused row-block kernels built from three tile primitives
+//   (1) gather-sum of 128-channel rows into a 32 x 128 LDS tile,
+//   (2) 32 x 128 x K tile GEMM on v_mfma_f32_32x32x2_f32 (exact fp32 fma chain),
+//   (3) per-row GroupNorm(1,128) / ReLU / residual over the LDS tile.
+// Workgroup tile = 32 rows x 128 output channels; wave w of the 4 MFMA waves
+// owns output channels [32w, 32w+32) and streams its own slice of the packed
+// weight straight from L2 to registers (no wave shares a weight element);
+// the A operand (gathered rows) is the shared, LDS-resident one.
+#include "lgcn_common.hpp"
+
+namespace lgcn {
+
+constexpr int kTileFloats = kTM * kLDA;  // one 32 x (128+4) LDS tile
+
+// acc[32 x 32 block of this wave] += A[32 x 8*nq] * Wpacked
+// A operand of 32x32x2: lane l holds A[l & 31][k = l >> 5]; B operand holds
+// B[k = l >> 5][l & 31].  With one float4 per lane per 8 k's, step j of the
+// q-th group contracts k = 8q + 4(l >> 5) + j on both operands.
+__device__ __forceinline__ void tile_gemm(const float *__restrict__ A, const float4 *__restrict__ wp_wave,
+                                          f32x16 &acc, int lane, int nq) {
+    const float *arow = A + (lane & 31) * kLDA + 4 * (lane >> 5);
+    const float4 *b = wp_wave + lane;
+#pragma unroll 4
+    for (int q = 0; q < nq; ++q) {
+        const float4 a = *reinterpret_cast<const float4 *>(arow + 8 * q);
+        const float4 w = b[q * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, w.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, w.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, w.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, w.w, acc, 0, 0, 0);
+    }
+}
+
+// C/D layout of 32x32: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+__device__ __forceinline__ int acc_row(int reg, int lane) { return (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ void acc_to_lds(float *T, const f32x16 &acc, int lane, int wave) {
+    float *p = T + 32 * wave + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) p[acc_row(i, lane) * kLDA] = acc[i];
+}
+
+// Row phase: thread (row = t >> 3, sub = t & 7) of the 256 compute threads
+// owns columns 4*sub + 32*j + {0..3}, j = 0..3 of its row (8 threads write
+// 128 contiguous bytes per j when the row goes to global memory).
+struct RowVals { float4 v[4]; };
+
+__device__ __forceinline__ RowVals row_load(const float *T, int t) {
+    RowVals r;
+    const float *p = T + (t >> 3) * kLDA + 4 * (t & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.v[j] = *reinterpret_cast<const float4 *>(p + 32 * j);
+    return r;
+}
+
+__device__ __forceinline__ void row_store_lds(float *T, int t, const RowVals &r) {
+    float *p = T + (t >> 3) * kLDA + 4 * (t & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(p + 32 * j) = r.v[j];
+}
+
+__device__ __forceinline__ float sum8(float x) {  // over the 8 lanes that share a row
+    x += __shfl_xor(x, 1, 64);
+    x += __shfl_xor(x, 2, 64);
+    x += __shfl_xor(x, 4, 64);
+    return x;
+}
+
+// GroupNorm(1, 128): per-row mean / biased variance over the 128 channels
+// (layers.py:73, gcd(1, n_out) = 1 group), two-pass in registers.
+__device__ __forceinline__ void row_gn(RowVals &r, int t, const float *__restrict__ g,
+                                       const float *__restrict__ b, float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w);
+    const float mean = sum8(s) * (1.0f / kC);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float a = r.v[j].x - mean, bb = r.v[j].y - mean, c = r.v[j].z - mean, d = r.v[j].w - mean;
+        q += (a * a + bb * bb) + (c * c + d * d);
+    }
+    const float rstd = 1.0f / sqrtf(sum8(q) * (1.0f / kC) + eps);
+    const int c0 = 4 * (t & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 gg = *reinterpret_cast<const float4 *>(g + c0 + 32 * j);
+        const float4 bb = *reinterpret_cast<const float4 *>(b + c0 + 32 * j);
+        r.v[j].x = (r.v[j].x - mean) * rstd * gg.x + bb.x;
+        r.v[j].y = (r.v[j].y - mean) * rstd * gg.y + bb.y;
+        r.v[j].z = (r.v[j].z - mean) * rstd * gg.z + bb.z;
+        r.v[j].w = (r.v[j].w - mean) * rstd * gg.w + bb.w;
+    }
+}
+
+__device__ __forceinline__ void row_relu(RowVals &r) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.v[j].x = fmaxf(r.v[j].x, 0.f); r.v[j].y = fmaxf(r.v[j].y, 0.f);
+        r.v[j].z = fmaxf(r.v[j].z, 0.f); r.v[j].w = fmaxf(r.v[j].w, 0.f);
+    }
+}
+
+__device__ __forceinline__ void row_add_global(RowVals &r, const float *__restrict__ rowp, int t) {
+    const float *p = rowp + 4 * (t & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 x = *reinterpret_cast<const float4 *>(p + 32 * j);
+        r.v[j].x += x.x; r.v[j].y += x.y; r.v[j].z += x.z; r.v[j].w += x.w;
+    }
+}
+
+__device__ __forceinline__ void row_store_global(float *__restrict__ rowp, int t, const RowVals &r) {
+    float *p = rowp + 4 * (t & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(p + 32 * j) = r.v[j];
+}
+
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ------------------------------------------------------------ packing -----
+__global__ __launch_bounds__(256) void k_pack_weight(const float *__restrict__ W, int ld, int k_real, int k_pad,
+                                                     float *__restrict__ out) {
+    const int nq = k_pad >> 3;
+    const int total = 4 * nq * 64 * 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % nq, w = (i >> 8) / nq;
+        const int row = 32 * w + (lane & 31), k = 8 * q + 4 * (lane >> 5) + j;
+        out[i] = k < k_real ? W[(int64_t)row * ld + k] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------ agg_mlp -----
+// 8 waves: waves 0-3 run the MFMA chain of relation i while waves 4-7 gather
+// relation i+1 into the other LDS buffer (one barrier per relation).
+__device__ __forceinline__ void gather_rel(float *__restrict__ Abuf, const lgcn_agg_mlp_t &p, int ri, int tile,
+                                           int gt /*0..255*/) {
+    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(p.rel[ri].src);
+    const int mode = p.rel[ri].mode;
+    const int hw = gt >> 5, l = gt & 31;
+    int b[4], e[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int row = it * 8 + hw;
+        const int64_t n = (int64_t)tile * kTM + row;
+        b[it] = 0; e[it] = 0;
+        if (n < p.n_rows) {
+            if (mode == LGCN_REL_CSR) {
+                const int64_t k = ((int64_t)tile * p.n_rel_csr + p.rel[ri].ridx) * 32 + row;
+                b[it] = p.rowptr[k]; e[it] = p.rowptr[k + 1];
+            } else if (mode == LGCN_REL_RANGE) {
+                b[it] = p.rowptr[n]; e[it] = p.rowptr[n + 1];
+            } else {
+                b[it] = (int)n; e[it] = (int)n + 1;
+            }
+        }
+    }
+    float4 s[4];
+    // first edge of each of the 4 rows: independent loads in flight together
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        s[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b[it] < e[it]) {
+            const int idx = mode == LGCN_REL_CSR ? p.col[b[it]] : b[it];
+            s[it] = src[(int64_t)idx * 32 + l];
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        int j = b[it] + 1;
+        for (; j + 1 < e[it]; j += 2) {  // two loads in flight, summed in index order
+            const int i0 = mode == LGCN_REL_CSR ? p.col[j] : j;
+            const int i1 = mode == LGCN_REL_CSR ? p.col[j + 1] : j + 1;
+            const float4 x0 = src[(int64_t)i0 * 32 + l];
+            const float4 x1 = src[(int64_t)i1 * 32 + l];
+            s[it] = f4add(f4add(s[it], x0), x1);
+        }
+        if (j < e[it]) {
+            const int i0 = mode == LGCN_REL_CSR ? p.col[j] : j;
+            s[it] = f4add(s[it], src[(int64_t)i0 * 32 + l]);
+        }
+        *reinterpret_cast<float4 *>(Abuf + (it * 8 + hw) * kLDA + 4 * l) = s[it];
+    }
+}
+
+__global__ __launch_bounds__(512) void k_agg_mlp(const lgcn_agg_mlp_t p, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * kTileFloats + 32];
+    float *buf0 = smem, *buf1 = smem + kTileFloats;
+    int *act = reinterpret_cast<int *>(smem + 2 * kTileFloats);  // [0..15] relation ids, [16] count
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_chunk_remap(blockIdx.x, n_tiles);
+    const int64_t row0 = (int64_t)tile * kTM;
+
+    // active relations of this tile (a relation with no edge into the tile
+    // contributes an all-zero A tile: skip its gather and its MFMAs)
+    if (wave == 0) {
+        bool on = false;
+        if (lane < p.n_rel) {
+            const int mode = p.rel[lane].mode;
+            if (mode == LGCN_REL_CSR) {
+                const int64_t k0 = ((int64_t)tile * p.n_rel_csr + p.rel[lane].ridx) * 32;
+                on = p.rowptr[k0 + 32] > p.rowptr[k0];
+            } else if (mode == LGCN_REL_RANGE) {
+                const int64_t r1 = row0 + kTM < p.n_rows ? row0 + kTM : p.n_rows;
+                on = p.rowptr[r1] > p.rowptr[row0];
+            } else {
+                on = true;
+            }
+        }
+        const unsigned long long m = __ballot(on);
+        if (on) act[__popcll(m & ((1ull << lane) - 1ull))] = lane;
+        if (lane == 0) act[16] = __popcll(m);
+    }
+    __syncthreads();
+    const int nact = __builtin_amdgcn_readfirstlane(act[16]);
+
+    if (wave >= 4 && nact > 0) gather_rel(buf0, p, __builtin_amdgcn_readfirstlane(act[0]), tile, tid - 256);
+    __syncthreads();
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (int i = 0; i < nact; ++i) {
+        float *cur = (i & 1) ? buf1 : buf0;
+        float *nxt = (i & 1) ? buf0 : buf1;
+        if (wave < 4) {
+            const int ri = __builtin_amdgcn_readfirstlane(act[i]);
+            tile_gemm(cur, reinterpret_cast<const float4 *>(p.rel[ri].wp) + wave * (16 * 64), acc, lane, 16);
+        } else if (i + 1 < nact) {
+            gather_rel(nxt, p, __builtin_amdgcn_readfirstlane(act[i + 1]), tile, tid - 256);
+        }
+        __syncthreads();
+    }
+
+    if (wave < 4) {
+        if (p.w4 != nullptr) {
+            // rank-4 update: the 4 extra input channels of A2M.meta (lanegcn.py:387-395)
+            const float4 wc = *reinterpret_cast<const float4 *>(p.w4 + 4 * (32 * wave + (lane & 31)));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t n = row0 + acc_row(i, lane);
+                if (n < p.n_rows) {
+                    const float2 tu = reinterpret_cast<const float2 *>(p.x4_a)[n];
+                    acc[i] += tu.x * wc.x + tu.y * wc.y + p.x4_b[n] * wc.z + p.x4_c[n] * wc.w;
+                }
+            }
+        }
+        acc_to_lds(buf0, acc, lane, wave);
+    }
+    __syncthreads();
+
+    const int rrow = tid >> 3;  // valid for tid < 256
+    const int64_t n = row0 + rrow;
+    const bool live = tid < 256 && n < p.n_rows;
+    const int flags = p.flags;
+
+    if (!(flags & LGCN_F_GEMM2)) {
+        if (tid < 256) {
+            RowVals r = row_load(buf0, tid);
+            if (live && p.out_pre) row_store_global(p.out_pre + n * kC, tid, r);
+            if (flags & LGCN_F_GN1) row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
+            if (live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
+            if (flags & LGCN_F_RELU1) row_relu(r);
+            if (live) row_store_global(p.out + n * kC, tid, r);
+        }
+        return;
+    }
+
+    if (tid < 256) {
+        RowVals r = row_load(buf0, tid);
+        if (live && p.out_pre) row_store_global(p.out_pre + n * kC, tid, r);
+        if (flags & LGCN_F_GN1) row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
+        if (flags & LGCN_F_RELU1) row_relu(r);
+        row_store_lds(buf0, tid, r);
+    }
+    __syncthreads();
+    if (wave < 4) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        tile_gemm(buf0, reinterpret_cast<const float4 *>(p.wp2) + wave * (16 * 64), acc, lane, 16);
+        acc_to_lds(buf1, acc, lane, wave);
+    }
+    __syncthreads();
+    if (tid < 256) {
+        RowVals r = row_load(buf1, tid);
+        if (flags & LGCN_F_GN2) row_gn(r, tid, p.gn2_g, p.gn2_b, p.eps);
+        if (live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
+        if (flags & LGCN_F_RELU2) row_relu(r);
+        if (live) row_store_global(p.out + n * kC, tid, r);
+    }
+}
+
+// ------------------------------------------------------- mapnet input -----
+// h1[row][c] = ReLU(w1[c][0] * x + w1[c][1] * y + b1[c]) for the thread's 16 columns
+__device__ __forceinline__ void lin2_relu_to_lds(float *T, int t, float x, float y, const float *__restrict__ w1,
+                                                 const float *__restrict__ b1) {
+    float *p = T + (t >> 3) * kLDA + 4 * (t & 7);
+    const int c0 = 4 * (t & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + 32 * j;
+        const float4 wa = *reinterpret_cast<const float4 *>(w1 + 2 * c);      // (c,0) (c,1) (c+1,0) (c+1,1)
+        const float4 wb = *reinterpret_cast<const float4 *>(w1 + 2 * c + 4);  // c+2, c+3
+        const float4 bb = *reinterpret_cast<const float4 *>(b1 + c);
+        float4 o;
+        o.x = fmaxf(x * wa.x + y * wa.y + bb.x, 0.f);
+        o.y = fmaxf(x * wa.z + y * wa.w + bb.y, 0.f);
+        o.z = fmaxf(x * wb.x + y * wb.y + bb.z, 0.f);
+        o.w = fmaxf(x * wb.z + y * wb.w + bb.w, 0.f);
+        *reinterpret_cast<float4 *>(p + 32 * j) = o;
+    }
+}
+
+struct InputParams {
+    const float *ctrs, *feats;
+    int64_t n_rows;
+    const float *wa1, *ba1, *wpa2, *ga, *bta;
+    const float *ws1, *bs1, *wps2, *gs, *bts;
+    float eps;
+    float *out;
+};
+
+__global__ __launch_bounds__(256) void k_mapnet_input(const InputParams p, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * kTileFloats];
+    float *T1 = smem, *T2 = smem + kTileFloats;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = blockIdx.x;
+    const int64_t n = (int64_t)tile * kTM + (tid >> 3);
+    const bool live = n < p.n_rows;
+    f32x16 acc;
+
+    float2 c = make_float2(0.f, 0.f), f = make_float2(0.f, 0.f);
+    if (live) { c = reinterpret_cast<const float2 *>(p.ctrs)[n]; f = reinterpret_cast<const float2 *>(p.feats)[n]; }
+
+    lin2_relu_to_lds(T1, tid, c.x, c.y, p.wa1, p.ba1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    tile_gemm(T1, reinterpret_cast<const float4 *>(p.wpa2) + wave * (16 * 64), acc, lane, 16);
+    acc_to_lds(T2, acc, lane, wave);
+    __syncthreads();
+    RowVals ra = row_load(T2, tid);
+    row_gn(ra, tid, p.ga, p.bta, p.eps);
+
+    lin2_relu_to_lds(T1, tid, f.x, f.y, p.ws1, p.bs1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    tile_gemm(T1, reinterpret_cast<const float4 *>(p.wps2) + wave * (16 * 64), acc, lane, 16);
+    acc_to_lds(T2, acc, lane, wave);
+    __syncthreads();
+    RowVals rs = row_load(T2, tid);
+    row_gn(rs, tid, p.gs, p.bts, p.eps);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) rs.v[j] = f4add(rs.v[j], ra.v[j]);
+    row_relu(rs);
+    if (live) row_store_global(p.out + n * kC, tid, rs);
+}
+
+// ---------------------------------------------------------- att pairs -----
+struct PairParams {
+    const float *agt_ctrs, *ctx_ctrs;
+    const int32_t *hi, *wi, *n_pairs;
+    int64_t cap;
+    const float *wd0, *bd0, *wpd2, *gd, *btd;
+    const float *wpc0e, *U, *V, *gc, *btc;
+    float eps;
+    float *m;
+};
+
+__global__ __launch_bounds__(256) void k_att_pairs(const PairParams p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * kTileFloats];
+    float *T1 = smem, *T2 = smem + kTileFloats;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t P = *p.n_pairs;
+    if (P < 0 || P > p.cap) P = p.cap;
+    const int64_t n_tiles = (P + kTM - 1) / kTM;
+    f32x16 acc;
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t pr = tile * kTM + (tid >> 3);
+        const bool live = pr < P;
+        int h = 0, w = 0;
+        float dx = 0.f, dy = 0.f;
+        if (live) {
+            h = p.hi[pr]; w = p.wi[pr];
+            const float2 a = reinterpret_cast<const float2 *>(p.agt_ctrs)[h];
+            const float2 c = reinterpret_cast<const float2 *>(p.ctx_ctrs)[w];
+            dx = a.x - c.x; dy = a.y - c.y;
+        }
+        lin2_relu_to_lds(T1, tid, dx, dy, p.wd0, p.bd0);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        tile_gemm(T1, reinterpret_cast<const float4 *>(p.wpd2) + wave * (16 * 64), acc, lane, 16);
+        acc_to_lds(T2, acc, lane, wave);
+        __syncthreads();
+        {
+            RowVals r = row_load(T2, tid);
+            row_gn(r, tid, p.gd, p.btd, p.eps);
+            row_relu(r);
+            row_store_lds(T2, tid, r);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        tile_gemm(T2, reinterpret_cast<const float4 *>(p.wpc0e) + wave * (16 * 64), acc, lane, 16);
+        acc_to_lds(T1, acc, lane, wave);
+        __syncthreads();
+        {
+            RowVals r = row_load(T1, tid);
+            if (live) {
+                row_add_global(r, p.U + (int64_t)h * kC, tid);
+                row_add_global(r, p.V + (int64_t)w * kC, tid);
+            }
+            row_gn(r, tid, p.gc, p.btc, p.eps);
+            row_relu(r);
+            if (live) row_store_global(p.m + pr * kC, tid, r);
+        }
+        // next iteration's first write to T1 is by the same thread that just
+        // read those elements; T2 is rewritten only after the next barrier.
+    }
+}
+
+}  // namespace lgcn
+
+using namespace lgcn;
+
+extern "C" {
+
+int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad, float *out, void *stream) {
+    LGCN_CHECK_PTR(W); LGCN_CHECK_PTR(out);
+    if (k_real < 1 || k_pad < k_real || (k_pad & 7) || ld < k_real) return LGCN_EINVAL;
+    LGCN_CHECK_ALIGN16(out);
+    const int total = kC * k_pad;
+    hipLaunchKernelGGL(k_pack_weight, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, ld, k_real, k_pad, out);
+    return launch_status();
+}
+
+int lgcn_agg_mlp(const lgcn_agg_mlp_t *ph, void *stream) {
+    LGCN_CHECK_PTR(ph);
+    const lgcn_agg_mlp_t &p = *ph;
+    if (p.n_rows < 0 || p.n_rel < 1 || p.n_rel > LGCN_MAX_REL) return LGCN_EINVAL;
+    if (p.n_rows == 0) return LGCN_OK;
+    if (p.n_rows > 0x7fffffff) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(p.out); LGCN_CHECK_ALIGN16(p.out);
+    bool need_rowptr = false, need_col = false;
+    for (int r = 0; r < p.n_rel; ++r) {
+        LGCN_CHECK_PTR(p.rel[r].src); LGCN_CHECK_PTR(p.rel[r].wp);
+        LGCN_CHECK_ALIGN16(p.rel[r].src); LGCN_CHECK_ALIGN16(p.rel[r].wp);
+        switch (p.rel[r].mode) {
+            case LGCN_REL_IDENT: break;
+            case LGCN_REL_CSR:
+                if (p.rel[r].ridx < 0 || p.rel[r].ridx >= p.n_rel_csr) return LGCN_EINVAL;
+                need_rowptr = need_col = true; break;
+            case LGCN_REL_RANGE: need_rowptr = true; break;
+            default: return LGCN_EINVAL;
+        }
+    }
+    if (need_rowptr) LGCN_CHECK_PTR(p.rowptr);
+    if (need_col) LGCN_CHECK_PTR(p.col);
+    if (p.flags & LGCN_F_GN1) { LGCN_CHECK_PTR(p.gn1_g); LGCN_CHECK_PTR(p.gn1_b); LGCN_CHECK_ALIGN16(p.gn1_g); LGCN_CHECK_ALIGN16(p.gn1_b); }
+    if (p.flags & LGCN_F_GEMM2) { LGCN_CHECK_PTR(p.wp2); LGCN_CHECK_ALIGN16(p.wp2); }
+    if (p.flags & LGCN_F_GN2) {
+        if (!(p.flags & LGCN_F_GEMM2)) return LGCN_EINVAL;
+        LGCN_CHECK_PTR(p.gn2_g); LGCN_CHECK_PTR(p.gn2_b); LGCN_CHECK_ALIGN16(p.gn2_g); LGCN_CHECK_ALIGN16(p.gn2_b);
+    }
+    if ((p.flags & LGCN_F_RELU2) && !(p.flags & LGCN_F_GEMM2)) return LGCN_EINVAL;
+    if (p.flags & LGCN_F_RES) { LGCN_CHECK_PTR(p.res); LGCN_CHECK_ALIGN16(p.res); }
+    if (p.w4) { LGCN_CHECK_PTR(p.x4_a); LGCN_CHECK_PTR(p.x4_b); LGCN_CHECK_PTR(p.x4_c); LGCN_CHECK_ALIGN16(p.w4); }
+    if (p.out_pre) LGCN_CHECK_ALIGN16(p.out_pre);
+    const int n_tiles = (int)((p.n_rows + kTM - 1) / kTM);
+    hipLaunchKernelGGL(k_agg_mlp, dim3(n_tiles), dim3(512), 0, (hipStream_t)stream, p, n_tiles);
+    return launch_status();
+}
+
+int lgcn_mapnet_input(const float *ctrs, const float *feats, int64_t n_rows, const float *wa1, const float *ba1,
+                      const float *wpa2, const float *ga, const float *bta, const float *ws1, const float *bs1,
+                      const float *wps2, const float *gs, const float *bts, float eps, float *out, void *stream) {
+    if (n_rows < 0) return LGCN_EINVAL;
+    if (n_rows == 0) return LGCN_OK;
+    if (n_rows > 0x7fffffff) return LGCN_ESHAPE;
+    const void *ptrs[] = {ctrs, feats, wa1, ba1, wpa2, ga, bta, ws1, bs1, wps2, gs, bts, out};
+    for (const void *q : ptrs) LGCN_CHECK_PTR(q);
+    const void *al[] = {wa1, ba1, wpa2, ga, bta, ws1, bs1, wps2, gs, bts, out};
+    for (const void *q : al) LGCN_CHECK_ALIGN16(q);
+    InputParams p{ctrs, feats, n_rows, wa1, ba1, wpa2, ga, bta, ws1, bs1, wps2, gs, bts, eps, out};
+    const int n_tiles = (int)((n_rows + kTM - 1) / kTM);
+    hipLaunchKernelGGL(k_mapnet_input, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, p, n_tiles);
+    return launch_status();
+}
+
+int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs, const int32_t *hi, const int32_t *wi,
+                   const int32_t *n_pairs, int64_t cap, const float *wd0, const float *bd0, const float *wpd2,
+                   const float *gd, const float *btd, const float *wpc0e, const float *U, const float *V,
+                   const float *gc, const float *btc, float eps, float *m, void *stream) {
+    if (cap < 0) return LGCN_EINVAL;
+    if (cap == 0) return LGCN_OK;
+    if (cap > 0x7ffffff0) return LGCN_ESHAPE;
+    const void *ptrs[] = {agt_ctrs, ctx_ctrs, hi, wi, n_pairs, wd0, bd0, wpd2, gd, btd, wpc0e, U, V, gc, btc, m};
+    for (const void *q : ptrs) LGCN_CHECK_PTR(q);
+    const void *al[] = {wd0, bd0, wpd2, gd, btd, wpc0e, U, V, gc, btc, m};
+    for (const void *q : al) LGCN_CHECK_ALIGN16(q);
+    PairParams p{agt_ctrs, ctx_ctrs, hi, wi, n_pairs, cap, wd0, bd0, wpd2, gd, btd, wpc0e, U, V, gc, btc, eps, m};
+    int64_t tiles = (cap + kTM - 1) / kTM;
+    const unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
+    hipLaunchKernelGGL(k_att_pairs, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,257 @@
+"""Tensor-level wrappers over the C ABI (include/lgcn.h).
+
+Every function takes CUDA (ROCm) tensors, enqueues on the current torch stream and returns
+without synchronising.  CPU tensors are rejected: the product path has no CPU fallback.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib as L
+
+C_FEAT = 128
+TM = 32
+EPS = 1e-5
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t: torch.Tensor, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise L.LgcnError("%s must be a CUDA tensor (the HIP hot path has no CPU fallback)" % name)
+    if dtype is not None and t.dtype != dtype:
+        raise L.LgcnError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _no_grad_guard(*tensors):
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise L.LgcnError(
+            "the HIP hot path is forward-only in this release: call it under torch.no_grad() "
+            "(silently dropping gradients would be wrong)"
+        )
+
+
+# ------------------------------------------------------------------ integer path
+def graph_gather_indices(flat_in: torch.Tensor, seg_off: torch.Tensor, seg_base: torch.Tensor, want32=False):
+    """out[e] = in[e] + base[seg(e)] (lanegcn.py:191-208).  Returns (out64, out32|None)."""
+    lib = L.load()
+    flat_in = _dev(flat_in, torch.int64, "flat_in")
+    seg_off = _dev(seg_off, torch.int64, "seg_off")
+    seg_base = _dev(seg_base, torch.int64, "seg_base")
+    n = flat_in.numel()
+    out64 = torch.empty_like(flat_in)
+    out32 = torch.empty(n, dtype=torch.int32, device=flat_in.device) if want32 else None
+    L.check(lib.lgcn_graph_gather(_ptr(flat_in), n, _ptr(seg_off), _ptr(seg_base), seg_base.numel(),
+                                  _ptr(out64), _ptr(out32), _stream()), "lgcn_graph_gather")
+    return out64, out32
+
+
+@dataclass
+class LanePlan:
+    """Tile-major CSR-by-destination of the lane relations (see include/lgcn.h)."""
+    rowptr: torch.Tensor
+    col: torch.Tensor
+    n_rel: int
+    n_nodes: int
+    n_edges: List[int]
+
+
+def csr_build(u_list: Sequence[torch.Tensor], v_list: Sequence[torch.Tensor], n_nodes: int) -> LanePlan:
+    lib = L.load()
+    n_rel = len(u_list)
+    if n_rel < 1 or n_rel > L.MAX_REL or len(v_list) != n_rel:
+        raise L.LgcnError("csr_build: need 1..%d relations" % L.MAX_REL)
+    us = [_dev(u, torch.int64, "u") for u in u_list]
+    vs = [_dev(v, torch.int64, "v") for v in v_list]
+    ne = [int(u.numel()) for u in us]
+    for u, v in zip(us, vs):
+        if u.numel() != v.numel():
+            raise L.LgcnError("csr_build: u and v differ in length")
+    dev = us[0].device
+    nk1 = lib.lgcn_csr_rowptr_elems(n_nodes, n_rel)
+    rowptr = torch.empty(nk1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(sum(ne), 1), dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.lgcn_csr_ws_elems(n_nodes, n_rel), dtype=torch.int32, device=dev)
+    up = (C.c_void_p * n_rel)(*[u.data_ptr() if u.numel() else 0 for u in us])
+    vp = (C.c_void_p * n_rel)(*[v.data_ptr() if v.numel() else 0 for v in vs])
+    nn = (C.c_int64 * n_rel)(*ne)
+    L.check(lib.lgcn_csr_build(up, vp, nn, n_rel, n_nodes, _ptr(rowptr), _ptr(col), _ptr(ws), _stream()),
+            "lgcn_csr_build")
+    return LanePlan(rowptr, col, n_rel, n_nodes, ne)
+
+
+@dataclass
+class PairSet:
+    """Result of the Att pair search (lanegcn.py:672-689) kept on device."""
+    hi: torch.Tensor          # [cap] int32, first P valid
+    wi: torch.Tensor          # [cap] int32
+    n_pairs: torch.Tensor     # [1] int32 (device)
+    rowptr: torch.Tensor      # [T+1] int32: segments of index_add_(0, hi, .)
+    cap: int
+    n_agt: int
+    agt_ctrs: torch.Tensor    # [T,2] concatenated centres
+    ctx_ctrs: torch.Tensor    # [S,2]
+    _p_host: Optional[int] = None
+
+    def count(self) -> int:
+        """P on the host (one device->host read, cached)."""
+        if self._p_host is None:
+            self._p_host = int(self.n_pairs.item())
+            if self._p_host < 0:
+                raise L.LgcnError("pair capacity %d exceeded (P = %d)" % (self.cap, -self._p_host))
+        return self._p_host
+
+    def hi_wi_long(self):
+        """(hi, wi) as the reference's LongTensors [P] (test/debug accessor; syncs once)."""
+        lib = L.load()
+        P = self.count()
+        h = torch.empty(self.cap, dtype=torch.int64, device=self.hi.device)
+        w = torch.empty_like(h)
+        L.check(lib.lgcn_widen_i32(_ptr(self.hi), _ptr(self.n_pairs), self.cap, _ptr(h), _stream()), "lgcn_widen_i32")
+        L.check(lib.lgcn_widen_i32(_ptr(self.wi), _ptr(self.n_pairs), self.cap, _ptr(w), _stream()), "lgcn_widen_i32")
+        return h[:P], w[:P]
+
+
+def pairs_build(agt_ctrs: torch.Tensor, agt_off: torch.Tensor, ctx_ctrs: torch.Tensor, ctx_off: torch.Tensor,
+                dist_th: float, cap: int, legacy_offsets: bool = True) -> PairSet:
+    lib = L.load()
+    agt_ctrs = _dev(agt_ctrs, torch.float32, "agt_ctrs")
+    ctx_ctrs = _dev(ctx_ctrs, torch.float32, "ctx_ctrs")
+    agt_off = _dev(agt_off, torch.int32, "agt_off")
+    ctx_off = _dev(ctx_off, torch.int32, "ctx_off")
+    B = agt_off.numel() - 1
+    if ctx_off.numel() != B + 1 or B < 1:
+        raise L.LgcnError("pairs_build: offset tables must both have B+1 entries")
+    T, S = agt_ctrs.shape[0], ctx_ctrs.shape[0]
+    dev = agt_ctrs.device
+    hi = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+    wi = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
+    n_pairs = torch.empty(1, dtype=torch.int32, device=dev)
+    rowptr = torch.empty(T + 1, dtype=torch.int32, device=dev)
+    ws = torch.empty(lib.lgcn_pairs_ws_elems(T, B), dtype=torch.int32, device=dev)
+    L.check(lib.lgcn_pairs_build(_ptr(agt_ctrs), _ptr(agt_off), _ptr(ctx_ctrs), _ptr(ctx_off), B, T, S,
+                                 float(dist_th), int(bool(legacy_offsets)), _ptr(hi), _ptr(wi), cap,
+                                 _ptr(n_pairs), _ptr(rowptr), _ptr(ws), _stream()), "lgcn_pairs_build")
+    return PairSet(hi, wi, n_pairs, rowptr, cap, T, agt_ctrs, ctx_ctrs)
+
+
+# ------------------------------------------------------------------ weight packing
+_pack_cache = {}
+
+
+def packed(weight: torch.Tensor, col0: int = 0, k: Optional[int] = None) -> torch.Tensor:
+    """MFMA-packed image of weight[:, col0:col0+k] ([128, k] slice of an nn.Linear weight).
+
+    Cached per (storage, version, slice): repacked only after the parameter is modified in place."""
+    lib = L.load()
+    w = _dev(weight.detach(), torch.float32, "weight")
+    if w.dim() != 2 or w.shape[0] != C_FEAT:
+        raise L.LgcnError("packed(): weight must be [128, K]")
+    k = w.shape[1] - col0 if k is None else k
+    key = (w.device.index, w.data_ptr(), col0, k)
+    ver = weight._version
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    k_pad = (k + 7) // 8 * 8
+    out = torch.empty(C_FEAT * k_pad, dtype=torch.float32, device=w.device)
+    src = w[:, col0:]
+    L.check(lib.lgcn_pack_weight(C.c_void_p(src.data_ptr()), w.stride(0), k, k_pad, _ptr(out), _stream()),
+            "lgcn_pack_weight")
+    _pack_cache[key] = (ver, out)
+    return out
+
+
+def cols4(weight: torch.Tensor, col0: int) -> torch.Tensor:
+    """Contiguous [128, 4] copy of weight[:, col0:col0+4] (the 4 meta columns of A2M.meta), cached."""
+    key = (weight.device.index, weight.data_ptr(), col0, "c4")
+    ver = weight._version
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    out = weight.detach()[:, col0:col0 + 4].contiguous()
+    _pack_cache[key] = (ver, out)
+    return out
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+# ------------------------------------------------------------------ fp path
+@dataclass
+class RelSpec:
+    src: torch.Tensor
+    wp: torch.Tensor
+    mode: int = L.REL_IDENT
+    ridx: int = 0
+
+
+def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, col=None, n_rel_csr=0,
+            gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, eps=EPS):
+    """Fused aggregate -> GEMM -> GN -> ReLU -> GEMM -> GN -> +res -> ReLU row block (lgcn_agg_mlp)."""
+    lib = L.load()
+    if not rels or len(rels) > L.MAX_REL:
+        raise L.LgcnError("agg_mlp: 1..%d relations" % L.MAX_REL)
+    dev = rels[0].src.device
+    p = L.AggMlp()
+    p.n_rows, p.n_rel, p.n_rel_csr, p.flags, p.eps = n_rows, len(rels), n_rel_csr, flags, eps
+    keep = []
+    for i, r in enumerate(rels):
+        s = _dev(r.src, torch.float32, "rel.src")
+        keep.append(s)
+        p.rel[i].src, p.rel[i].wp, p.rel[i].mode, p.rel[i].ridx = s.data_ptr(), r.wp.data_ptr(), r.mode, r.ridx
+    p.rowptr = 0 if rowptr is None else rowptr.data_ptr()
+    p.col = 0 if col is None else col.data_ptr()
+    if w4 is not None:
+        xa, xb, xc = (_dev(t, torch.float32, "x4") for t in x4)
+        w4 = _dev(w4, torch.float32, "w4")
+        keep += [xa, xb, xc, w4]
+        p.x4_a, p.x4_b, p.x4_c, p.w4 = xa.data_ptr(), xb.data_ptr(), xc.data_ptr(), w4.data_ptr()
+    if gn1 is not None:
+        p.gn1_g, p.gn1_b = gn1[0].data_ptr(), gn1[1].data_ptr()
+    if wp2 is not None:
+        p.wp2 = wp2.data_ptr()
+    if gn2 is not None:
+        p.gn2_g, p.gn2_b = gn2[0].data_ptr(), gn2[1].data_ptr()
+    if res is not None:
+        res = _dev(res, torch.float32, "res")
+        p.res = res.data_ptr()
+    if out is None:
+        out = torch.empty((n_rows, C_FEAT), dtype=torch.float32, device=dev)
+    p.out = out.data_ptr()
+    p.out_pre = 0 if out_pre is None else out_pre.data_ptr()
+    L.check(lib.lgcn_agg_mlp(C.byref(p), _stream()), "lgcn_agg_mlp")
+    return out
+
+
+def mapnet_input(ctrs, feats, wa1, ba1, wpa2, gn_a, ws1, bs1, wps2, gn_s, eps=EPS):
+    lib = L.load()
+    ctrs = _dev(ctrs, torch.float32, "ctrs")
+    feats = _dev(feats, torch.float32, "feats")
+    n = ctrs.shape[0]
+    out = torch.empty((n, C_FEAT), dtype=torch.float32, device=ctrs.device)
+    L.check(lib.lgcn_mapnet_input(_ptr(ctrs), _ptr(feats), n, _ptr(wa1), _ptr(ba1), _ptr(wpa2), _ptr(gn_a[0]),
+                                  _ptr(gn_a[1]), _ptr(ws1), _ptr(bs1), _ptr(wps2), _ptr(gn_s[0]), _ptr(gn_s[1]),
+                                  eps, _ptr(out), _stream()), "lgcn_mapnet_input")
+    return out
+
+
+def att_pairs(ps: PairSet, wd0, bd0, wpd2, gn_d, wpc0e, U, V, gn_c, m=None, eps=EPS):
+    lib = L.load()
+    if m is None:
+        m = torch.empty((max(ps.cap, 1), C_FEAT), dtype=torch.float32, device=U.device)
+    L.check(lib.lgcn_att_pairs(_ptr(ps.agt_ctrs), _ptr(ps.ctx_ctrs), _ptr(ps.hi), _ptr(ps.wi), _ptr(ps.n_pairs),
+                               ps.cap, _ptr(wd0), _ptr(bd0), _ptr(wpd2), _ptr(gn_d[0]), _ptr(gn_d[1]), _ptr(wpc0e),
+                               _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _ptr(m), _stream()),
+            "lgcn_att_pairs")
+    return m

@@ -1,0 +1,309 @@
+"""GPU: the HIP hot path (through the C ABI / ctypes) against the oracle and the reference captures.
+
+Bars: index work bit-exact; fp32 features max|delta| <= 1e-4 (BASELINE.json north_star)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import to_torch_scene
+from golden_io import load_scenes
+from oracle import lanegcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+FTOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import lanegcn as M
+    from lanegcn_amd import ops
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return M, ops
+
+
+def make_modules(M, sd, device="cuda"):
+    mods = {}
+    for name, cls in (("map_net", M.MapNet), ("a2m", M.A2M), ("m2m", M.M2M), ("m2a", M.M2A), ("a2a", M.A2A)):
+        m = cls(M.config)
+        sub = {k[len(name) + 1:]: v for k, v in sd.items() if k.startswith(name + ".")}
+        m.load_state_dict(sub, strict=True)
+        mods[name] = m.to(device).eval()
+    return mods
+
+
+def run_hot_path(M, mods, scenes, actors):
+    """Device forward of the five stages; returns dict of CPU numpy outputs + the graph dict."""
+    with torch.no_grad():
+        graph = M.graph_gather([s["graph"] for s in scenes])
+        actor_ctrs = [s["ctrs"].cuda() for s in scenes]
+        sizes = [len(c) for c in actor_ctrs]
+        actor_idcs, st = [], 0
+        for n in sizes:
+            actor_idcs.append(torch.arange(st, st + n, device="cuda"))
+            st += n
+        actors = actors.cuda()
+        out = {}
+        nodes, node_idcs, node_ctrs = mods["map_net"](graph)
+        out["map_net"] = nodes
+        nodes = mods["a2m"](nodes, graph, actors, actor_idcs, actor_ctrs)
+        out["a2m"] = nodes
+        nodes = mods["m2m"](nodes, graph)
+        out["m2m"] = nodes
+        act = mods["m2a"](actors, actor_idcs, actor_ctrs, nodes, node_idcs, node_ctrs)
+        out["m2a"] = act
+        act = mods["a2a"](act, actor_idcs, actor_ctrs)
+        out["a2a"] = act
+        torch.cuda.synchronize()
+    return {k: v.cpu().numpy() for k, v in out.items()}, graph
+
+
+@pytest.fixture(scope="module")
+def gcase(golden, ref_state_names, hip):
+    M, _ = hip
+    scenes = [to_torch_scene(s) for s in load_scenes(golden)]
+    sd = O.seeded_state(ref_state_names, int(golden["seed"]))
+    return scenes, sd, make_modules(M, sd)
+
+
+def test_graph_gather_bit_exact(gcase, golden, hip):
+    M, _ = hip
+    scenes, _, _ = gcase
+    graph = M.graph_gather([s["graph"] for s in scenes])
+    for k1 in ("pre", "suc"):
+        for i in range(6):
+            for k2 in ("u", "v"):
+                got = graph[k1][i][k2]
+                assert got.dtype == torch.int64
+                assert np.array_equal(got.cpu().numpy(), golden["gg/%s/%d/%s" % (k1, i, k2)])
+    for k1 in ("left", "right"):
+        for k2 in ("u", "v"):
+            assert np.array_equal(graph[k1][k2].cpu().numpy(), golden["gg/%s/%s" % (k1, k2)])
+    assert [len(x) for x in graph["idcs"]] == [s["graph"]["num_nodes"] for s in scenes]
+
+
+def test_graph_gather_int16_and_gpu_inputs(gcase, golden, hip):
+    """int16 on-disk indices (preprocess_data.py:230-238) through to_long, and scenes already on the GPU."""
+    M, _ = hip
+    from lanegcn_amd.utils import gpu, to_long
+    scenes, _, _ = gcase
+
+    def cast16(g):
+        g = dict(g)
+        for k1 in ("pre", "suc"):
+            g[k1] = [{k: v.to(torch.int16) for k, v in d.items()} for d in g[k1]]
+        for k1 in ("left", "right"):
+            g[k1] = {k: v.to(torch.int16) for k, v in g[k1].items()}
+        return g
+
+    graph = M.graph_gather(to_long(gpu([cast16(s["graph"]) for s in scenes])))
+    assert np.array_equal(graph["pre"][3]["u"].cpu().numpy(), golden["gg/pre/3/u"])
+    assert np.array_equal(graph["right"]["v"].cpu().numpy(), golden["gg/right/v"])
+
+
+def expand_plan(plan):
+    """CSR plan -> sorted list of (relation, u, v)."""
+    rp = plan.rowptr.cpu().numpy().astype(np.int64)
+    col = plan.col.cpu().numpy()
+    out = []
+    n_tiles = (plan.n_nodes + 31) // 32
+    for t in range(n_tiles):
+        for r in range(plan.n_rel):
+            for j in range(32):
+                k = (t * plan.n_rel + r) * 32 + j
+                for e in range(rp[k], rp[k + 1]):
+                    out.append((r, t * 32 + j, int(col[e])))
+    return sorted(out)
+
+
+def test_csr_plan_is_the_coo_multiset(gcase, hip):
+    M, _ = hip
+    scenes, _, _ = gcase
+    graph = M.graph_gather([s["graph"] for s in scenes])
+    plan = M.lane_plan(graph)
+    want = []
+    r = 0
+    for i in range(6):
+        for k1 in ("pre", "suc"):
+            u, v = graph[k1][i]["u"].cpu().numpy(), graph[k1][i]["v"].cpu().numpy()
+            want += [(r, int(a), int(b)) for a, b in zip(u, v)]
+            r += 1
+    for k1 in ("left", "right"):
+        u, v = graph[k1]["u"].cpu().numpy(), graph[k1]["v"].cpu().numpy()
+        want += [(r, int(a), int(b)) for a, b in zip(u, v)]
+        r += 1
+    assert expand_plan(plan) == sorted(want)
+    rp = plan.rowptr.cpu().numpy()
+    assert rp[0] == 0 and rp[-1] == len(want) and np.all(np.diff(rp) >= 0)
+
+
+def test_csr_duplicates_and_unsorted_edges(hip):
+    _, ops = hip
+    rng = np.random.default_rng(5)
+    n = 77
+    us = [torch.from_numpy(rng.integers(0, n, m)).cuda() for m in (0, 40, 300)]
+    vs = [torch.from_numpy(rng.integers(0, n, m)).cuda() for m in (0, 40, 300)]
+    plan = ops.csr_build(us, vs, n)
+    want = sorted((r, int(a), int(b)) for r in range(3) for a, b in zip(us[r].cpu().numpy(), vs[r].cpu().numpy()))
+    assert expand_plan(plan) == want
+
+
+def test_pairs_bit_exact_vs_reference(gcase, golden, hip):
+    M, _ = hip
+    scenes, _, _ = gcase
+    graph = M.graph_gather([s["graph"] for s in scenes])
+    actor_ctrs = [s["ctrs"].cuda() for s in scenes]
+    actor_idcs = [torch.arange(len(c)) for c in actor_ctrs]
+    cases = {"a2m": (graph["idcs"], graph["ctrs"], actor_idcs, actor_ctrs, 7.0),
+             "m2a": (actor_idcs, actor_ctrs, graph["idcs"], graph["ctrs"], 6.0),
+             "a2a": (actor_idcs, actor_ctrs, actor_idcs, actor_ctrs, 100.0)}
+    for name, (ai, ac, ci, cc, th) in cases.items():
+        ps = M.build_pairs(ai, ac, ci, cc, th)
+        hi, wi = ps.hi_wi_long()
+        assert hi.dtype == torch.int64
+        assert np.array_equal(hi.cpu().numpy(), golden["pairs/%s/hi" % name]), name
+        assert np.array_equal(wi.cpu().numpy(), golden["pairs/%s/wi" % name]), name
+        # rowptr = segments of index_add_(0, hi, .)
+        rp = ps.rowptr.cpu().numpy()
+        want = np.searchsorted(golden["pairs/%s/hi" % name], np.arange(len(rp)), side="left")
+        assert np.array_equal(rp, want), name
+
+
+def test_pairs_threshold_boundary_and_modes(hip):
+    """Integer-grid centres put many distances exactly ON the threshold (3-4-5 triangles): the fp32
+    no-FMA evaluation must agree with the oracle pair for pair, in legacy and fixed offset modes."""
+    M, _ = hip
+    rng = np.random.default_rng(9)
+    agt = [torch.from_numpy(rng.integers(-6, 7, (n, 2)).astype(np.float32)) for n in (70, 3, 130, 1)]
+    ctx = [torch.from_numpy(rng.integers(-6, 7, (n, 2)).astype(np.float32)) for n in (65, 4, 200, 2)]
+    ctx[1] = ctx[1] + 500.0   # scene 1 without pairs
+    ai = [torch.arange(len(a)) for a in agt]
+    ci = [torch.arange(len(c)) for c in ctx]
+    for legacy in (True, False):
+        hi_o, wi_o = O.pair_search(agt, ctx, 5.0, legacy)
+        ps = M.build_pairs(ai, [a.cuda() for a in agt], ci, [c.cuda() for c in ctx], 5.0, legacy)
+        hi, wi = ps.hi_wi_long()
+        assert np.array_equal(hi.cpu().numpy(), hi_o) and np.array_equal(wi.cpu().numpy(), wi_o)
+    # random real-valued centres, non-representable threshold
+    agt = [torch.from_numpy(rng.normal(0, 4, (n, 2)).astype(np.float32)) for n in (257, 64)]
+    ctx = [torch.from_numpy(rng.normal(0, 4, (n, 2)).astype(np.float32)) for n in (300, 129)]
+    hi_o, wi_o = O.pair_search(agt, ctx, 0.1 * 37)
+    ps = M.build_pairs([torch.arange(len(a)) for a in agt], [a.cuda() for a in agt],
+                       [torch.arange(len(c)) for c in ctx], [c.cuda() for c in ctx], 0.1 * 37)
+    hi, wi = ps.hi_wi_long()
+    assert np.array_equal(hi.cpu().numpy(), hi_o) and np.array_equal(wi.cpu().numpy(), wi_o)
+
+
+def test_stages_vs_reference_captures(gcase, golden, hip):
+    M, _ = hip
+    scenes, _, mods = gcase
+    out, _ = run_hot_path(M, mods, scenes, torch.from_numpy(golden["actors_in"]))
+    for k in ("map_net", "a2m", "m2m", "m2a", "a2a"):
+        err = float(np.abs(out[k] - golden[k]).max())
+        assert np.isfinite(out[k]).all() and err <= FTOL, (k, err)
+
+
+def test_each_stage_from_reference_inputs(gcase, golden, hip):
+    """Stage-by-stage: every module fed with the REFERENCE's input for that stage (no error carry-over)."""
+    M, _ = hip
+    scenes, _, mods = gcase
+    with torch.no_grad():
+        graph = M.graph_gather([s["graph"] for s in scenes])
+        actor_ctrs = [s["ctrs"].cuda() for s in scenes]
+        actor_idcs = [torch.arange(len(c), device="cuda") for c in actor_ctrs]
+        actors = torch.from_numpy(golden["actors_in"]).cuda()
+        g = lambda k: torch.from_numpy(golden[k]).cuda()
+        got = {
+            "a2m": mods["a2m"](g("map_net"), graph, actors, actor_idcs, actor_ctrs),
+            "m2m": mods["m2m"](g("a2m"), graph),
+            "m2a": mods["m2a"](actors, actor_idcs, actor_ctrs, g("m2m"), graph["idcs"], graph["ctrs"]),
+            "a2a": mods["a2a"](g("m2a"), actor_idcs, actor_ctrs),
+        }
+    for k, v in got.items():
+        err = float(np.abs(v.cpu().numpy() - golden[k]).max())
+        assert err <= FTOL, (k, err)
+
+
+def test_att_empty_context_branch(gcase, golden, hip):
+    M, _ = hip
+    scenes, _, mods = gcase
+    with torch.no_grad():
+        graph = M.graph_gather([s["graph"] for s in scenes])
+        nodes = torch.from_numpy(golden["map_net"]).cuda()
+        out = mods["a2m"].att[0](nodes, graph["idcs"], graph["ctrs"], torch.zeros(0, 128, device="cuda"), [], [], 7.0)
+    assert float(np.abs(out.cpu().numpy() - golden["att_empty_ctx"]).max()) <= FTOL
+
+
+def test_error_behaviour_matches_reference(gcase, hip):
+    M, _ = hip
+    scenes, sd, mods = gcase
+    from lanegcn_amd import data as gen
+    with torch.no_grad():
+        # all scenes pair-less -> RuntimeError like torch.cat([]) (lanegcn.py:688)
+        graph = M.graph_gather([s["graph"] for s in scenes])
+        far = [s["ctrs"].cuda() + 1.0e4 for s in scenes]
+        idcs = [torch.arange(len(c)) for c in far]
+        nodes = torch.zeros(sum(len(x) for x in graph["idcs"]), 128, device="cuda")
+        with pytest.raises(RuntimeError):
+            mods["a2m"].att[0](nodes, graph["idcs"], graph["ctrs"], torch.zeros(sum(len(c) for c in far), 128, device="cuda"),
+                               idcs, far, 7.0)
+        # chains shorter than 33 nodes -> KeyError (lanegcn.py:312-322)
+        short = to_torch_scene(gen.synth_scene(np.random.default_rng(0), [2], 3))
+        with pytest.raises(KeyError):
+            mods["map_net"](M.graph_gather([short["graph"]]))
+    # CPU tensors are refused: there is no CPU fallback
+    from lanegcn_amd._lib import LgcnError
+    with pytest.raises(LgcnError):
+        mods["m2m"].cpu()(torch.zeros(4, 128), {})
+    mods["m2m"].cuda()
+    # autograd is refused rather than silently dropped
+    with pytest.raises(LgcnError):
+        mods["m2m"](torch.zeros(4, 128, device="cuda", requires_grad=True), {})
+
+
+def test_s2_batch_vs_oracle_and_properties(hip, ref_state_names):
+    """BASELINE size (32 scenes, 10,368 nodes, 1,600 actors): HIP vs oracle within 1e-4, bitwise
+    run-to-run repeatability, and scene-order equivariance (scenes are independent graphs)."""
+    M, _ = hip
+    from lanegcn_amd import data as gen
+    sd = O.seeded_state(ref_state_names, 3)
+    mods = make_modules(M, sd)
+    scenes_np = gen.synth_batch("S2", seed=1)
+    scenes = [to_torch_scene(s) for s in scenes_np]
+    A = sum(len(s["ctrs"]) for s in scenes)
+    actors = torch.from_numpy(np.random.default_rng(2).normal(0, 1, (A, 128)).astype(np.float32)).relu()
+    out, graph = run_hot_path(M, mods, scenes, actors)
+    assert out["map_net"].shape == (10368, 128) and out["a2a"].shape == (1600, 128)
+
+    torch.set_num_threads(max(1, (torch.get_num_threads())))
+    want = O.hot_path(O.graph_gather([s["graph"] for s in scenes]), actors, [s["ctrs"] for s in scenes], sd)
+    for k in ("map_net", "a2m", "m2m", "m2a", "a2a"):
+        err = float(np.abs(out[k] - want[k].numpy()).max())
+        assert err <= FTOL, (k, err)
+
+    out2, _ = run_hot_path(M, mods, scenes, actors)
+    for k in out:
+        assert np.array_equal(out[k], out2[k]), "not bitwise repeatable: " + k
+
+    # reverse the scene order: per-scene outputs must come back identical
+    rev = scenes[::-1]
+    a_rev = torch.cat([actors[50 * i:50 * (i + 1)] for i in range(31, -1, -1)])
+    out_r, _ = run_hot_path(M, mods, rev, a_rev)
+    for i in (0, 7, 31):
+        j = 31 - i
+        assert np.allclose(out["m2m"][324 * i:324 * (i + 1)], out_r["m2m"][324 * j:324 * (j + 1)], atol=2e-5)
+        assert np.allclose(out["a2a"][50 * i:50 * (i + 1)], out_r["a2a"][50 * j:50 * (j + 1)], atol=2e-5)
+
+
+def test_ragged_tail_tile(hip, ref_state_names):
+    """Node / actor counts that are not multiples of the 32-row tile, single scene."""
+    M, _ = hip
+    from lanegcn_amd import data as gen
+    sd = O.seeded_state(ref_state_names, 5)
+    mods = make_modules(M, sd)
+    sc = to_torch_scene(gen.synth_scene(np.random.default_rng(4), [5, 4], 7))   # 162 nodes, 7 actors
+    actors = torch.from_numpy(np.random.default_rng(6).normal(0, 1, (7, 128)).astype(np.float32))
+    out, _ = run_hot_path(M, mods, [sc], actors)
+    want = O.hot_path(O.graph_gather([sc["graph"]]), actors, [sc["ctrs"]], sd)
+    for k in out:
+        assert float(np.abs(out[k] - want[k].numpy()).max()) <= FTOL, k
