@@ -1,0 +1,233 @@
+#!/usr/bin/env python
+"""Headline benchmark: Argoverse-shaped scenes/s, forward, batch = 32 (~10 k lane nodes) per GPU.
+
+One "step" = one pass of the hot path (graph_gather -> CSR plan -> MapNet -> A2M -> M2M -> M2A ->
+A2A) over one 32-scene synthetic batch (workload S2: 10,368 lane nodes, 110,592
+edges, 1,600 actors) whose flat input buffers are already resident in HBM.  The forward is captured
+once in a hipGraph and replayed per step.  N > 1: one process per GPU (torchrun), every rank runs its
+own batch (scenes are independent graphs: no data-path collective), value = all scenes / max time.
+
+Prints ONE JSON line on rank 0 (contract in the task brief) carrying `roofline` for the dominant
+kernel (the fused LaneConv layer, k_agg_mlp) and `cpu_baseline` (the oracle = CPU restatement of the
+reference on the same batch, timed on this box's host cores, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+C = 128
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBPS = 8000.0             # HBM3E spec
+
+
+def measured_traffic(workload):
+    """HBM bytes per LaneConv launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their
+    own runs, gfx950 corrections of MI355X_MICROARCH.md applied) committed under profiles/; None when
+    no summary for this workload exists."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(workload, {}).get("laneconv_hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def laneconv_algorithmic(n_nodes, sum_e):
+    """flops and bytes of ONE LaneConv layer launch (fp32, s = 4)."""
+    flops = 2 * C * C * (n_nodes + sum_e) + 2 * C * C * n_nodes
+    byts = 4 * C * n_nodes + 4 * C * sum_e + 8 * sum_e + 16 * 4 * C * C + 4 * C * n_nodes + 16 * C
+    return flops, byts
+
+
+def build_modules(seed, device):
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import lanegcn as M
+    torch.manual_seed(seed)
+    mods = dict(map_net=M.MapNet(M.config), a2m=M.A2M(M.config), m2m=M.M2M(M.config),
+                m2a=M.M2A(M.config), a2a=M.A2A(M.config))
+    return {k: m.to(device).eval() for k, m in mods.items()}
+
+
+def log(msg):
+    print("[bench %s] %s" % (time.strftime("%H:%M:%S"), msg), file=sys.stderr, flush=True)
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity, capped by the cgroup CPU quota and by the
+    16-core share a one-GPU box grants."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("LGCN_BENCH_MAX_CORES", "16"))))
+
+
+def cpu_baseline(scenes, actors_cpu, mods, budget_s):
+    """The oracle (kind "port": CPU restatement pinned to the reference's own outputs) on the same
+    batch, all host cores of this process, bounded to ~budget_s seconds."""
+    from oracle import lanegcn_oracle as O            # checker / baseline only
+    from lanegcn_amd import data as gen
+    sd = {}
+    for name, m in mods.items():
+        for k, v in m.state_dict().items():
+            sd["%s.%s" % (name, k)] = v.detach().cpu()
+    tscenes = [gen.from_numpy(s) for s in scenes]
+    actor_ctrs = [s["ctrs"] for s in tscenes]
+
+    def one():
+        g = O.graph_gather([s["graph"] for s in tscenes])
+        return O.hot_path(g, actors_cpu, actor_ctrs, sd)
+
+    cores = host_cores()
+    res = {}
+    for label, nt, share in (("all", cores, 0.7), ("1t", 1, 0.3)):
+        torch.set_num_threads(nt)
+        log("cpu baseline: %d thread(s)" % nt)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            one()                                                   # warm-up
+            log("cpu baseline warm-up run %.2f s" % (time.perf_counter() - t0))
+            times, t_start = [], time.perf_counter()
+            while len(times) < 2 or (time.perf_counter() - t_start < budget_s * share and len(times) < 50):
+                t0 = time.perf_counter()
+                one()
+                times.append(time.perf_counter() - t0)
+        res[label] = (float(np.median(times)), len(times))
+    n = len(scenes)
+    return {
+        "value": n / res["all"][0], "unit": "scenes/s", "cores": cores, "kind": "port",
+        "sample": "oracle hot path (graph_gather+MapNet+A2M+M2M+M2A+A2A) on the same %d-scene batch, "
+                  "median of %d runs at %d torch threads" % (n, res["all"][1], cores),
+        "ms_per_batch": res["all"][0] * 1e3,
+        "value_1_thread": n / res["1t"][0], "ms_per_batch_1_thread": res["1t"][0] * 1e3,
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="S2", choices=["S0", "S1", "S2"])
+    ap.add_argument("--scenes", type=int, default=None, help="override scenes per batch (S2: 32)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torchrun (one process per GPU)" % args.gpus)
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the hot path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import data as gen
+    from lanegcn_amd import dist as D
+    from lanegcn_amd import ops
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+    from lanegcn_amd.engine import HotPathEngine, collate_flat
+
+    mods = build_modules(1234, dev)            # same random-init weights on every rank
+    scenes = gen.synth_batch(args.workload, seed=100 + rank, n_scenes=args.scenes)
+    fb = collate_flat(scenes, dev)
+    actors_cpu = torch.from_numpy(
+        np.random.default_rng(7 + rank).normal(0, 1, (fb.n_actors, C)).astype(np.float32)).relu()
+    actors = actors_cpu.to(dev)
+    eng = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"])
+
+    log("rank %d: batch ready (N=%d nodes, A=%d actors, sumE=%d)" % (rank, fb.n_nodes, fb.n_actors, sum(fb.n_edges)))
+    if args.no_graph:
+        step = lambda: eng.forward(fb, actors)
+        for _ in range(3):
+            step()
+    else:
+        graph, _ = eng.capture(fb, actors)
+        step = graph.replay
+
+    barrier = D.barrier
+
+    log("rank %d: forward %s" % (rank, "eager" if args.no_graph else "captured in a hipGraph"))
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)     # slowest rank
+
+    log("rank %d: %d steps in %.4f s" % (rank, args.steps, elapsed))
+    # per-kernel durations (HIP events on the launch stream), eager launches of the same forward
+    with ops.kernel_timer() as kt:
+        for _ in range(10):
+            eng.forward(fb, actors)
+    ksum = kt.summary()
+    if rank == 0:
+        st = eng.forward(fb, actors, stages=True)
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(v).all() for v in st.values())
+
+    if rank == 0:
+        n_scenes = len(scenes)
+        sum_e = sum(fb.n_edges)
+        lc_ms = float(np.mean(ksum["laneconv"]))
+        flops, byts = laneconv_algorithmic(fb.n_nodes, sum_e)
+        ach = flops / (lc_ms * 1e-3) / 1e12
+        line = {
+            "metric": "Argoverse scenes/sec forward (batch=32, ~10k lane nodes)",
+            "value": args.gpus * n_scenes * args.steps / elapsed,
+            "unit": "scenes/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s: hot path forward (graph_gather+CSR plan+MapNet+A2M+M2M+M2A+A2A), "
+                                   "%d scenes/GPU, %d lane nodes, %d edges, %d actors, random-init weights, "
+                                   "inputs resident in HBM, %s" % (args.workload, n_scenes, fb.n_nodes, sum_e,
+                                                                    fb.n_actors,
+                                                                    "eager" if args.no_graph else "hipGraph replay"),
+                       "scenes_per_gpu": n_scenes, "parallelism": "dp%d (independent scene shards)" % args.gpus},
+            "roofline": {
+                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(args.workload),
+                "kernel": "lgcn::k_agg_mlp<1> (fused LaneConv layer, 8 launches/step)",
+                "avg_launch_us": lc_ms * 1e3, "algorithmic_flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": byts,
+                "hbm_frac_algorithmic": byts / (lc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
+            },
+            "kernel_avg_us": {k: float(np.mean(v)) * 1e3 for k, v in ksum.items()},
+        }
+        if args.cpu_seconds > 0:
+            line["cpu_baseline"] = cpu_baseline(scenes, actors_cpu, mods, args.cpu_seconds)
+            line["speedup_vs_cpu_all_cores"] = line["value"] / args.gpus / line["cpu_baseline"]["value"]
+        print(json.dumps(line), flush=True)
+    barrier()
+    if world > 1:
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

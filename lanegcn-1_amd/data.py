@@ -133,3 +133,20 @@ def synth_batch(kind="S2", seed=0, n_scenes=None, idx_dtype=np.int64):
     if kind == "S2":
         return [synth_scene(rng, [6] * 3, 50, idx_dtype=idx_dtype) for _ in range(n_scenes or 32)]
     raise ValueError(kind)
+
+
+class SyntheticArgoDataset(torch.utils.data.Dataset):
+    """Stands in for ArgoDataset(split, config, train) (reference data.py:16-361, needs argoverse-api and
+    the dataset, both absent): same constructor signature and item schema, scenes from synth_scene."""
+
+    def __init__(self, split=None, config=None, train=True, length=64, roads=(6, 6, 6), n_actors=50, seed=0):
+        self.config, self.train = config, train
+        self.length, self.roads, self.n_actors, self.seed = int(length), list(roads), n_actors, seed
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        scene = synth_scene(np.random.default_rng(self.seed * 1000003 + idx), self.roads, self.n_actors)
+        scene["idx"] = idx
+        return scene

@@ -1,0 +1,93 @@
+"""One-process-per-GPU helpers over torch.distributed (backend "nccl" = RCCL over xGMI on ROCm;
+"gloo" for the CPU tests).  Forward throughput shards scenes across ranks with NO data-path
+collective (scenes are independent graphs); the only exchange of a training step is
+the gradient average, done on ONE flat bucket (the reference averages 405 tensors through Horovod,
+train.py:66-69)."""
+import os
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+def env_ranks():
+    """(rank, world_size, local_rank) from the torchrun environment (1-process defaults)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")),
+            int(os.environ.get("LOCAL_RANK", "0")))
+
+
+def is_on() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def barrier():
+    if is_on():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device="cpu") -> float:
+    """Slowest rank's time: the whole job is as fast as its slowest shard."""
+    if not is_on():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float, device="cpu") -> float:
+    if not is_on():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def job_throughput(units_this_rank: float, elapsed_this_rank: float, device="cpu") -> float:
+    """Whole-job units/s: all ranks' units over the MAX elapsed time."""
+    return sum_over_ranks(units_this_rank, device) / max_over_ranks(elapsed_this_rank, device)
+
+
+def shard(n_items: int, rank: int, world: int, seed: int = 0, epoch: int = 0, shuffle: bool = True,
+          drop_last: bool = True) -> List[int]:
+    """Indices of this rank's shard with DistributedSampler semantics (train.py:119-131): one
+    seeded permutation shared by all ranks, rank r takes items r, r+world, ..."""
+    g = torch.Generator()
+    g.manual_seed(seed + epoch)
+    idx = torch.randperm(n_items, generator=g).tolist() if shuffle else list(range(n_items))
+    if drop_last:
+        idx = idx[: (n_items // world) * world]
+    else:
+        pad = (-len(idx)) % world
+        idx = idx + idx[:pad]
+    return idx[rank::world]
+
+
+def broadcast_parameters(tensors: Iterable[torch.Tensor], src: int = 0):
+    """hvd.broadcast_parameters(net.state_dict(), 0) (train.py:96,145) as one flat broadcast."""
+    tensors = [t for t in tensors]
+    if not is_on() or not tensors:
+        return
+    flat = torch.cat([t.detach().reshape(-1).float() for t in tensors])
+    dist.broadcast(flat, src)
+    off = 0
+    with torch.no_grad():
+        for t in tensors:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+def allreduce_mean_grads(params: Iterable[torch.nn.Parameter]):
+    """Average gradients over ranks (Horovod DistributedOptimizer semantics, train.py:66-69) with one
+    all-reduce over a single flat fp32 bucket (14.8 MB for the full net)."""
+    ps = [p for p in params if p.grad is not None]
+    if not is_on() or not ps:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat.div_(dist.get_world_size())
+    off = 0
+    for p in ps:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n

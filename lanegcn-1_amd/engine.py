@@ -1,0 +1,176 @@
+"""Lean forward engine of the hot path: flat, pre-collated device batch in, stage features out.
+
+``collate_flat`` does on the host, once per batch, what the reference spreads over ~1.3 k tiny
+H2D copies and casts (utils.gpu / utils.to_long, lanegcn.py:129-134): every per-scene array is
+concatenated into one flat buffer and uploaded with one copy per array.  ``HotPathEngine.forward``
+then runs graph_gather -> CSR plan -> MapNet -> A2M -> M2M -> M2A -> A2A with no host
+synchronisation and no data-dependent host control flow, so the whole forward can be captured in
+a hipGraph (``capture``) and replayed with one host call.
+"""
+from dataclasses import dataclass
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from . import ops
+from . import lanegcn as M
+
+
+@dataclass
+class FlatBatch:
+    """One batch of scenes, flat and device resident."""
+    n_scenes: int
+    n_nodes: int
+    n_actors: int
+    num_scales: int
+    node_ctrs: torch.Tensor     # [N,2]
+    node_feats: torch.Tensor    # [N,2]
+    turn: torch.Tensor          # [N,2]
+    control: torch.Tensor       # [N]
+    intersect: torch.Tensor     # [N]
+    actor_ctrs: torch.Tensor    # [A,2]
+    node_off: torch.Tensor      # [B+1] int32
+    actor_off: torch.Tensor     # [B+1] int32
+    idx_local: torch.Tensor     # [2*sumE] int64: scene-local u/v of every (relation, u|v, scene) segment
+    seg_off: torch.Tensor       # [S+1] int64
+    seg_base: torch.Tensor      # [S] int64: node offset of the segment's scene
+    rel_slices: List[tuple]     # per relation: ((u_begin, u_end), (v_begin, v_end)) into idx_local
+    cap_a2m: int                # sum_i n_i * a_i   (upper bound of the pair counts)
+    cap_a2a: int                # sum_i a_i * a_i
+    n_edges: List[int]
+
+
+def collate_flat(scenes: List[Dict], device=None) -> FlatBatch:
+    """Host collate of scene dicts (numpy or CPU torch leaves) into a FlatBatch on `device`."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+
+    def npy(x):
+        return x.numpy() if torch.is_tensor(x) else np.asarray(x)
+
+    graphs = [s["graph"] for s in scenes]
+    B = len(scenes)
+    ns = len(graphs[0]["pre"])
+    n_nodes = np.array([int(g["num_nodes"]) for g in graphs], np.int64)
+    n_act = np.array([len(s["ctrs"]) for s in scenes], np.int64)
+    node_off = np.zeros(B + 1, np.int64)
+    np.cumsum(n_nodes, out=node_off[1:])
+    actor_off = np.zeros(B + 1, np.int64)
+    np.cumsum(n_act, out=actor_off[1:])
+
+    pieces, seg_len, seg_base, rel_slices, n_edges = [], [], [], [], []
+    pos = 0
+
+    def add(getter):
+        nonlocal pos
+        begin = pos
+        for j, g in enumerate(graphs):
+            x = npy(getter(g)).astype(np.int64).reshape(-1)   # 0-dim guard (lanegcn.py:203-207) + to_long
+            pieces.append(x)
+            seg_len.append(len(x))
+            seg_base.append(node_off[j])
+            pos += len(x)
+        return (begin, pos)
+
+    keys = []
+    for i in range(ns):
+        keys += [("pre", i), ("suc", i)]
+    for k1, i in keys:
+        su = add(lambda g: g[k1][i]["u"])
+        sv = add(lambda g: g[k1][i]["v"])
+        rel_slices.append((su, sv))
+        n_edges.append(su[1] - su[0])
+    for k1 in ("left", "right"):
+        su = add(lambda g: g[k1]["u"])
+        sv = add(lambda g: g[k1]["v"])
+        rel_slices.append((su, sv))
+        n_edges.append(su[1] - su[0])
+    seg_off = np.zeros(len(seg_len) + 1, np.int64)
+    np.cumsum(seg_len, out=seg_off[1:])
+
+    def up(a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype)))
+        return t.pin_memory().to(dev, non_blocking=True)
+
+    cat = lambda key, src: np.concatenate([npy(s[key]) for s in src], 0)
+    return FlatBatch(
+        n_scenes=B, n_nodes=int(node_off[-1]), n_actors=int(actor_off[-1]), num_scales=ns,
+        node_ctrs=up(cat("ctrs", graphs), np.float32), node_feats=up(cat("feats", graphs), np.float32),
+        turn=up(cat("turn", graphs), np.float32), control=up(cat("control", graphs), np.float32),
+        intersect=up(cat("intersect", graphs), np.float32), actor_ctrs=up(cat("ctrs", scenes), np.float32),
+        node_off=up(node_off, np.int32), actor_off=up(actor_off, np.int32),
+        idx_local=up(np.concatenate(pieces) if pieces else np.zeros(0, np.int64)),
+        seg_off=up(seg_off), seg_base=up(np.asarray(seg_base, np.int64)),
+        rel_slices=rel_slices, cap_a2m=int(np.dot(n_nodes, n_act)), cap_a2a=int(np.dot(n_act, n_act)),
+        n_edges=n_edges,
+    )
+
+
+class HotPathEngine:
+    """graph_gather -> MapNet -> A2M -> M2M -> M2A -> A2A on the HIP kernels, sync-free."""
+
+    def __init__(self, map_net: M.MapNet, a2m: M.A2M, m2m: M.M2M, m2a: M.M2A, a2a: M.A2A, config=None,
+                 legacy_offsets: bool = True):
+        self.map_net, self.a2m, self.m2m, self.m2a, self.a2a = map_net, a2m, m2m, m2a, a2a
+        self.config = config or M.config
+        self.legacy_offsets = legacy_offsets
+
+    @torch.no_grad()
+    def forward(self, fb: FlatBatch, actors: torch.Tensor, stages: bool = False) -> Dict[str, torch.Tensor]:
+        """actors: [A,128] ActorNet output.  Returns {"nodes", "actors"} (+ every stage if stages)."""
+        cfg = self.config
+        out = {}
+        # graph_gather (lanegcn.py:171-209) + CSR plan
+        g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
+        us = [g64[a:b] for (a, b), _ in fb.rel_slices]
+        vs = [g64[a:b] for _, (a, b) in fb.rel_slices]
+        plan = ops.csr_build(us, vs, fb.n_nodes)
+        # MapNet (lanegcn.py:311-363)
+        feat = self.map_net.stem(fb.node_ctrs, fb.node_feats)
+        feat = M.lane_conv(self.map_net.fuse, feat, plan, fb.num_scales)
+        if stages:
+            out["map_net"] = feat
+        # A2M (lanegcn.py:385-407)
+        feat = self.a2m.fuse_meta(feat, fb.turn, fb.control, fb.intersect)
+        ps = ops.pairs_build(fb.node_ctrs, fb.node_off, fb.actor_ctrs, fb.actor_off, cfg["actor2map_dist"],
+                             fb.cap_a2m, self.legacy_offsets)
+        for att in self.a2m.att:
+            feat = att.run(feat, actors, ps)
+        if stages:
+            out["a2m"] = feat
+        # M2M (lanegcn.py:445-480)
+        feat = M.lane_conv(self.m2m.fuse, feat, plan, fb.num_scales)
+        if stages:
+            out["m2m"] = feat
+        # M2A (lanegcn.py:502-513)
+        ps = ops.pairs_build(fb.actor_ctrs, fb.actor_off, fb.node_ctrs, fb.node_off, cfg["map2actor_dist"],
+                             fb.cap_a2m, self.legacy_offsets)
+        act = actors
+        for att in self.m2a.att:
+            act = att.run(act, feat, ps)
+        if stages:
+            out["m2a"] = act
+        # A2A (lanegcn.py:534-545)
+        ps = ops.pairs_build(fb.actor_ctrs, fb.actor_off, fb.actor_ctrs, fb.actor_off, cfg["actor2actor_dist"],
+                             fb.cap_a2a, self.legacy_offsets)
+        for att in self.a2a.att:
+            act = att.run(act, act, ps)
+        if stages:
+            out["a2a"] = act
+        out["nodes"], out["actors"] = feat, act
+        return out
+
+    def capture(self, fb: FlatBatch, actors: torch.Tensor, warmup: int = 2):
+        """Capture one forward into a hipGraph.  Returns (graph, outputs); ``graph.replay()`` re-runs
+        the whole forward on the captured buffers (refill fb's tensors / `actors` in place first)."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.forward(fb, actors)       # also fills the weight-pack caches outside the capture
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward(fb, actors)
+        return graph, out

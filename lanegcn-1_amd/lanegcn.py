@@ -180,10 +180,9 @@ def _fuse_modules(n_map: int, num_scales: int, ng: int = 1) -> nn.ModuleDict:
     return nn.ModuleDict(fuse)
 
 
-def _lane_conv(fuse: nn.ModuleDict, feat: Tensor, graph: Dict) -> Tensor:
+def lane_conv(fuse: nn.ModuleDict, feat: Tensor, plan: ops.LanePlan, num_scales: int) -> Tensor:
     """4 LaneConv layers, one fused launch each (reference lanegcn.py:331-362 == 448-479)."""
-    plan = lane_plan(graph)
-    keys = rel_keys(len(graph["pre"]))
+    keys = rel_keys(num_scales)
     for i in range(len(fuse["ctr"])):
         rels = [ops.RelSpec(feat, ops.packed(fuse["ctr"][i].weight), L.REL_IDENT)]
         for r, key in enumerate(keys):
@@ -192,7 +191,7 @@ def _lane_conv(fuse: nn.ModuleDict, feat: Tensor, graph: Dict) -> Tensor:
         c2 = fuse["ctr2"][i]
         feat = ops.agg_mlp(feat.shape[0], rels, _FULL, rowptr=plan.rowptr, col=plan.col, n_rel_csr=plan.n_rel,
                            gn1=_gn(fuse["norm"][i]), wp2=ops.packed(c2.linear.weight), gn2=_gn(c2.norm),
-                           res=feat, eps=fuse["norm"][i].eps)
+                           res=feat, eps=fuse["norm"][i].eps, tag="laneconv")
     return feat
 
 
@@ -210,19 +209,22 @@ class MapNet(nn.Module):
         self.fuse = _fuse_modules(n_map, config["num_scales"])
         self.relu = nn.ReLU(inplace=True)
 
+    def stem(self, ctrs: Tensor, feats: Tensor) -> Tensor:
+        """ReLU(input(ctrs) + seg(feats)), one launch (reference lanegcn.py:324-327)."""
+        a, s = self.input, self.seg
+        return ops.mapnet_input(ctrs, feats,
+                                a[0].weight, a[0].bias, ops.packed(a[2].linear.weight), _gn(a[2].norm),
+                                s[0].weight, s[0].bias, ops.packed(s[2].linear.weight), _gn(s[2].norm),
+                                eps=a[2].norm.eps)
+
     def forward(self, graph):
         if (len(graph["feats"]) == 0 or len(graph["pre"][-1]["u"]) == 0 or len(graph["suc"][-1]["u"]) == 0):
             # the reference's early-return branch reads a key that graph_gather never sets
             # (lanegcn.py:312-322) and therefore raises KeyError; kept for error parity
             raise KeyError("node_idcs")
         _hot_guard(graph["feats"], *self.parameters())
-        ctrs = torch.cat(graph["ctrs"], 0)
-        a, s = self.input, self.seg
-        feat = ops.mapnet_input(ctrs, graph["feats"],
-                                a[0].weight, a[0].bias, ops.packed(a[2].linear.weight), _gn(a[2].norm),
-                                s[0].weight, s[0].bias, ops.packed(s[2].linear.weight), _gn(s[2].norm),
-                                eps=a[2].norm.eps)
-        feat = _lane_conv(self.fuse, feat, graph)
+        feat = self.stem(torch.cat(graph["ctrs"], 0), graph["feats"])
+        feat = lane_conv(self.fuse, feat, lane_plan(graph), len(graph["pre"]))
         return feat, graph["idcs"], graph["ctrs"]
 
 
@@ -237,7 +239,7 @@ class M2M(nn.Module):
 
     def forward(self, feat: Tensor, graph: Dict) -> Tensor:
         _hot_guard(feat, *self.parameters())
-        return _lane_conv(self.fuse, feat, graph)
+        return lane_conv(self.fuse, feat, lane_plan(graph), len(graph["pre"]))
 
 
 # ------------------------------------------------------------------ attention blocks
@@ -290,6 +292,12 @@ class Att(nn.Module):
                                                          self.legacy_offsets)
         if self.strict and ps.count() == 0:
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
+        return self.run(agts, ctx, ps)
+
+    def run(self, agts: Tensor, ctx: Tensor, ps: ops.PairSet) -> Tensor:
+        """The pair MLP + segment reduce + node epilogue for a given pair set (lanegcn.py:691-709)."""
+        T = agts.shape[0]
+        lin = self.linear
         c0 = self.ctx[0]
         # row-wise Linears commute with the gathers agts[hi] / ctx[wi]: evaluate them per node
         U = ops.agg_mlp(T, [ops.RelSpec(agts, ops.packed(self.query.linear.weight))],
@@ -303,7 +311,8 @@ class Att(nn.Module):
         rels = [ops.RelSpec(agts, ops.packed(self.agt.weight)),
                 ops.RelSpec(m, ops.packed(self.ctx[1].weight), L.REL_RANGE)]
         return ops.agg_mlp(T, rels, _FULL, rowptr=ps.rowptr, gn1=_gn(self.norm),
-                           wp2=ops.packed(lin.linear.weight), gn2=_gn(lin.norm), res=agts, eps=self.norm.eps)
+                           wp2=ops.packed(lin.linear.weight), gn2=_gn(lin.norm), res=agts, eps=self.norm.eps,
+                           tag="att_post")
 
 
 class A2M(nn.Module):
@@ -316,13 +325,18 @@ class A2M(nn.Module):
         self.meta = Linear(n_map + 4, n_map, norm="GN", ng=1)
         self.att = nn.ModuleList([Att(n_map, config["n_actor"]) for _ in range(2)])
 
+    def fuse_meta(self, feat: Tensor, turn: Tensor, control: Tensor, intersect: Tensor) -> Tensor:
+        """meta = Linear(132 -> 128)+GN+ReLU over cat(feat, turn, control, intersect) without
+        materialising the cat (reference lanegcn.py:387-395)."""
+        w = self.meta.linear.weight
+        return ops.agg_mlp(feat.shape[0], [ops.RelSpec(feat, ops.packed(w, 0, 128))], L.F_GN1 | L.F_RELU1,
+                           x4=(turn, control, intersect), w4=ops.cols4(w, 128),
+                           gn1=_gn(self.meta.norm), eps=self.meta.norm.eps)
+
     def forward(self, feat: Tensor, graph: Dict, actors: Tensor, actor_idcs: List[Tensor],
                 actor_ctrs: List[Tensor]) -> Tensor:
         _hot_guard(feat, actors, *self.parameters())
-        w = self.meta.linear.weight
-        feat = ops.agg_mlp(feat.shape[0], [ops.RelSpec(feat, ops.packed(w, 0, 128))], L.F_GN1 | L.F_RELU1,
-                           x4=(graph["turn"], graph["control"], graph["intersect"]), w4=ops.cols4(w, 128),
-                           gn1=_gn(self.meta.norm), eps=self.meta.norm.eps)
+        feat = self.fuse_meta(feat, graph["turn"], graph["control"], graph["intersect"])
         th = self.config["actor2map_dist"]
         ps = None
         if len(actors) > 0:
@@ -367,3 +381,223 @@ class A2A(nn.Module):
         for att in self.att:
             actors = att(actors, actor_idcs, actor_ctrs, actors, actor_idcs, actor_ctrs, th, pairs=ps)
         return actors
+
+
+# ------------------------------------------------------------------ rest of the plugin (outside the hot path)
+class ActorNet(nn.Module):
+    """1-D conv FPN over the 20-step actor tracks (reference lanegcn.py:212-263); stock ATen ops."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        n_in, widths = 3, [32, 64, 128]
+        groups = []
+        for i, w in enumerate(widths):
+            blocks = [Res1d(n_in, w, norm="GN", ng=1) if i == 0 else Res1d(n_in, w, stride=2, norm="GN", ng=1),
+                      Res1d(w, w, norm="GN", ng=1)]
+            groups.append(nn.Sequential(*blocks))
+            n_in = w
+        self.groups = nn.ModuleList(groups)
+        n = config["n_actor"]
+        self.lateral = nn.ModuleList([Conv1d(w, n, norm="GN", ng=1, act=False) for w in widths])
+        self.output = Res1d(n, n, norm="GN", ng=1)
+
+    def forward(self, actors: Tensor) -> Tensor:
+        pyramid, out = [], actors
+        for g in self.groups:
+            out = g(out)
+            pyramid.append(out)
+        out = self.lateral[-1](pyramid[-1])
+        for i in range(len(pyramid) - 2, -1, -1):
+            out = F.interpolate(out, scale_factor=2, mode="linear", align_corners=False)
+            out = out + self.lateral[i](pyramid[i])
+        return self.output(out)[:, :, -1]
+
+
+class AttDest(nn.Module):
+    """Destination-conditioned actor feature for the mode scores (reference lanegcn.py:713-737)."""
+
+    def __init__(self, n_agt: int):
+        super().__init__()
+        self.dist = nn.Sequential(nn.Linear(2, n_agt), nn.ReLU(inplace=True), Linear(n_agt, n_agt, norm="GN", ng=1))
+        self.agt = Linear(2 * n_agt, n_agt, norm="GN", ng=1)
+
+    def forward(self, agts: Tensor, agt_ctrs: Tensor, dest_ctrs: Tensor) -> Tensor:
+        n_agt, num_mods = agts.size(1), dest_ctrs.size(1)
+        d = (agt_ctrs.unsqueeze(1) - dest_ctrs).reshape(-1, 2)
+        h = self.dist[1](self.dist[0](d))
+        d = F.relu(F.group_norm(F.linear(h, self.dist[2].linear.weight), 1, self.dist[2].norm.weight,
+                                self.dist[2].norm.bias, self.dist[2].norm.eps))
+        a = agts.unsqueeze(1).expand(-1, num_mods, -1).reshape(-1, n_agt)
+        return self.agt(torch.cat((d, a), 1))
+
+
+class PredNet(nn.Module):
+    """6-mode trajectory regression + scoring head (reference lanegcn.py:575-631); stock ATen ops."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        n = config["n_actor"]
+        self.pred = nn.ModuleList([nn.Sequential(LinearRes(n, n, norm="GN", ng=1), nn.Linear(n, 2 * config["num_preds"]))
+                                   for _ in range(config["num_mods"])])
+        self.att_dest = AttDest(n)
+        self.cls = nn.Sequential(LinearRes(n, n, norm="GN", ng=1), nn.Linear(n, 1))
+
+    def forward(self, actors: Tensor, actor_idcs: List[Tensor], actor_ctrs: List[Tensor]) -> Dict[str, List[Tensor]]:
+        reg = torch.stack([head(actors) for head in self.pred], 1)
+        reg = reg.view(reg.size(0), reg.size(1), -1, 2)
+        ctrs = torch.cat(actor_ctrs, 0)
+        reg = reg + ctrs.view(-1, 1, 1, 2)        # the per-scene loop of :609-612 in one op (idcs partition the rows)
+        dest = reg[:, :, -1].detach()
+        cls = self.cls(self.att_dest(actors, ctrs, dest)).view(-1, self.config["num_mods"])
+        cls, order = cls.sort(1, descending=True)
+        rows = torch.arange(len(order), device=order.device).view(-1, 1).expand_as(order)
+        reg = reg[rows.reshape(-1), order.reshape(-1)].view(cls.size(0), cls.size(1), -1, 2)
+        return {"cls": [cls[i] for i in actor_idcs], "reg": [reg[i] for i in actor_idcs]}
+
+
+class Net(nn.Module):
+    """ActorNet -> [graph_gather -> MapNet -> A2M -> M2M -> M2A -> A2A] -> PredNet (reference lanegcn.py:94-151).
+    The bracketed part is the HIP hot path; input and output formats are the reference's."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.actor_net = ActorNet(config)
+        self.map_net = MapNet(config)
+        self.a2m = A2M(config)
+        self.m2m = M2M(config)
+        self.m2a = M2A(config)
+        self.a2a = A2A(config)
+        self.pred_net = PredNet(config)
+
+    def forward(self, data: Dict) -> Dict[str, List[Tensor]]:
+        actors, actor_idcs = actor_gather(gpu(data["feats"]))
+        actor_ctrs = gpu(data["ctrs"])
+        actors = self.actor_net(actors)
+        # graph_gather takes the scenes as they come (CPU or GPU, int16 or int64): one concatenation and
+        # one H2D per array instead of utils.gpu's per-leaf copies (lanegcn.py:134)
+        graph = graph_gather(to_long(data["graph"]))
+        nodes, node_idcs, node_ctrs = self.map_net(graph)
+        nodes = self.a2m(nodes, graph, actors, actor_idcs, actor_ctrs)
+        nodes = self.m2m(nodes, graph)
+        actors = self.m2a(actors, actor_idcs, actor_ctrs, nodes, node_idcs, node_ctrs)
+        actors = self.a2a(actors, actor_idcs, actor_ctrs)
+        out = self.pred_net(actors, actor_idcs, actor_ctrs)
+        rot, orig = gpu(data["rot"]), gpu(data["orig"])
+        for i in range(len(out["reg"])):        # back to world coordinates (:147-150)
+            out["reg"][i] = torch.matmul(out["reg"][i], rot[i]) + orig[i].view(1, 1, 1, -1)
+        return out
+
+
+class PredLoss(nn.Module):
+    """Max-margin mode classification + SmoothL1 regression of the closest mode (reference lanegcn.py:740-807)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.reg_loss = nn.SmoothL1Loss(reduction="sum")
+
+    def forward(self, out, gt_preds, has_preds):
+        cfg = self.config
+        cls, reg = torch.cat(list(out["cls"]), 0), torch.cat(list(out["reg"]), 0)
+        gt_preds, has_preds = torch.cat(list(gt_preds), 0), torch.cat(list(has_preds), 0)
+        zero = 0.0 * (cls.sum() + reg.sum())
+        loss_out = {"cls_loss": zero.clone(), "num_cls": 0, "reg_loss": zero.clone(), "num_reg": 0}
+        num_mods, num_preds = cfg["num_mods"], cfg["num_preds"]
+        # last observed step per actor; actors whose only observed step is t=0 are dropped
+        last = has_preds.float() + 0.1 * torch.arange(num_preds, device=has_preds.device).float() / float(num_preds)
+        max_last, last_idcs = last.max(1)
+        keep = max_last > 1.0
+        cls, reg, gt_preds, has_preds, last_idcs = cls[keep], reg[keep], gt_preds[keep], has_preds[keep], last_idcs[keep]
+        rows = torch.arange(len(last_idcs), device=last_idcs.device)
+        dist = torch.stack([torch.sqrt(((reg[rows, j, last_idcs] - gt_preds[rows, last_idcs]) ** 2).sum(1))
+                            for j in range(num_mods)], 1)
+        min_dist, min_idcs = dist.min(1)
+        mgn = cls[rows, min_idcs].unsqueeze(1) - cls
+        mask0 = (min_dist < cfg["cls_th"]).view(-1, 1)
+        mask1 = dist - min_dist.view(-1, 1) > cfg["cls_ignore"]
+        mgn = mgn[mask0 * mask1]
+        hit = mgn < cfg["mgn"]
+        loss_out["cls_loss"] += cfg["cls_coef"] * (cfg["mgn"] * hit.sum() - mgn[hit].sum())
+        loss_out["num_cls"] += hit.sum().item()
+        best = reg[rows, min_idcs]
+        loss_out["reg_loss"] += cfg["reg_coef"] * self.reg_loss(best[has_preds], gt_preds[has_preds])
+        loss_out["num_reg"] += has_preds.sum().item()
+        return loss_out
+
+
+class Loss(nn.Module):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.pred_loss = PredLoss(config)
+
+    def forward(self, out: Dict, data: Dict) -> Dict:
+        loss_out = self.pred_loss(out, gpu(data["gt_preds"]), gpu(data["has_preds"]))
+        loss_out["loss"] = (loss_out["cls_loss"] / (loss_out["num_cls"] + 1e-10)
+                            + loss_out["reg_loss"] / (loss_out["num_reg"] + 1e-10))
+        return loss_out
+
+
+def pred_metrics(preds, gt_preds, has_preds):
+    """ade1, fde1, ade, fde, min_idcs (reference lanegcn.py:883-899)."""
+    assert has_preds.all()
+    preds, gt_preds = np.asarray(preds, np.float32), np.asarray(gt_preds, np.float32)
+    err = np.sqrt(((preds - np.expand_dims(gt_preds, 1)) ** 2).sum(3))
+    ade1, fde1 = err[:, 0].mean(), err[:, 0, -1].mean()
+    min_idcs = err[:, :, -1].argmin(1)
+    best = err[np.arange(len(min_idcs)), min_idcs]
+    return ade1, fde1, best.mean(), best[:, -1].mean(), min_idcs
+
+
+class PostProcess(nn.Module):
+    """Collects the first actor's predictions per scene and prints ADE/FDE (reference lanegcn.py:824-880)."""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+
+    def forward(self, out, data):
+        return {"preds": [x[0:1].detach().cpu().numpy() for x in out["reg"]],
+                "gt_preds": [x[0:1].numpy() for x in data["gt_preds"]],
+                "has_preds": [x[0:1].numpy() for x in data["has_preds"]]}
+
+    def append(self, metrics: Dict, loss_out: Dict, post_out=None) -> Dict:
+        if len(metrics.keys()) == 0:
+            for key in loss_out:
+                if key != "loss":
+                    metrics[key] = 0.0
+            for key in post_out:
+                metrics[key] = []
+        for key, val in loss_out.items():
+            if key != "loss":
+                metrics[key] += val.item() if isinstance(val, torch.Tensor) else val
+        for key in post_out:
+            metrics[key] += post_out[key]
+        return metrics
+
+    def display(self, metrics, dt, epoch, lr=None):
+        if lr is not None:
+            print("Epoch %3.3f, lr %.5f, time %3.2f" % (epoch, lr, dt))
+        else:
+            print("************************* Validation, time %3.2f *************************" % dt)
+        cls = metrics["cls_loss"] / (metrics["num_cls"] + 1e-10)
+        reg = metrics["reg_loss"] / (metrics["num_reg"] + 1e-10)
+        ade1, fde1, ade, fde, _ = pred_metrics(np.concatenate(metrics["preds"], 0), np.concatenate(metrics["gt_preds"], 0),
+                                               np.concatenate(metrics["has_preds"], 0))
+        print("loss %2.4f %2.4f %2.4f, ade1 %2.4f, fde1 %2.4f, ade %2.4f, fde %2.4f"
+              % (cls + reg, cls, reg, ade1, fde1, ade, fde))
+        print()
+
+
+def get_model():
+    """The reference's plugin entry point (lanegcn.py:902-913; called by train.py:63-64, test.py:57):
+    (config, Dataset, collate_fn, net, loss, post_process, opt)."""
+    from .data import SyntheticArgoDataset
+    net = Net(config).cuda()
+    loss = Loss(config).cuda()
+    post_process = PostProcess(config).cuda()
+    opt = Optimizer(net.parameters(), config)
+    return config, SyntheticArgoDataset, collate_fn, net, loss, post_process, opt

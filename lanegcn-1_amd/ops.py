@@ -145,46 +145,92 @@ def pairs_build(agt_ctrs: torch.Tensor, agt_off: torch.Tensor, ctx_ctrs: torch.T
 
 
 # ------------------------------------------------------------------ weight packing
-_pack_cache = {}
+def _cached(weight: torch.Tensor, key, make):
+    """Per-tensor-object cache, valid while (data_ptr, _version) are unchanged.  Living on the
+    Parameter object itself, an entry can never be hit through a recycled device address of some
+    other tensor.  (Writes through ``param.data`` do not bump ``_version``: call
+    ``invalidate_packed(param)`` after such an edit.)"""
+    cache = weight.__dict__.setdefault("_lgcn_cache", {})
+    stamp = (weight.data_ptr(), weight._version, weight.device)
+    hit = cache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    out = make()
+    cache[key] = (stamp, out)
+    return out
+
+
+def invalidate_packed(weight: torch.Tensor):
+    weight.__dict__.pop("_lgcn_cache", None)
 
 
 def packed(weight: torch.Tensor, col0: int = 0, k: Optional[int] = None) -> torch.Tensor:
-    """MFMA-packed image of weight[:, col0:col0+k] ([128, k] slice of an nn.Linear weight).
-
-    Cached per (storage, version, slice): repacked only after the parameter is modified in place."""
+    """MFMA-packed image of weight[:, col0:col0+k] ([128, k] slice of an nn.Linear weight); cached
+    on the parameter and rebuilt only after the parameter changes."""
     lib = L.load()
-    w = _dev(weight.detach(), torch.float32, "weight")
-    if w.dim() != 2 or w.shape[0] != C_FEAT:
+    if weight.dim() != 2 or weight.shape[0] != C_FEAT:
         raise L.LgcnError("packed(): weight must be [128, K]")
-    k = w.shape[1] - col0 if k is None else k
-    key = (w.device.index, w.data_ptr(), col0, k)
-    ver = weight._version
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
-    k_pad = (k + 7) // 8 * 8
-    out = torch.empty(C_FEAT * k_pad, dtype=torch.float32, device=w.device)
-    src = w[:, col0:]
-    L.check(lib.lgcn_pack_weight(C.c_void_p(src.data_ptr()), w.stride(0), k, k_pad, _ptr(out), _stream()),
-            "lgcn_pack_weight")
-    _pack_cache[key] = (ver, out)
-    return out
+    k = weight.shape[1] - col0 if k is None else k
+
+    def make():
+        w = _dev(weight.detach(), torch.float32, "weight")
+        k_pad = (k + 7) // 8 * 8
+        out = torch.empty(C_FEAT * k_pad, dtype=torch.float32, device=w.device)
+        src = w[:, col0:]
+        L.check(lib.lgcn_pack_weight(C.c_void_p(src.data_ptr()), w.stride(0), k, k_pad, _ptr(out), _stream()),
+                "lgcn_pack_weight")
+        return out
+
+    return _cached(weight, ("pack", col0, k), make)
 
 
 def cols4(weight: torch.Tensor, col0: int) -> torch.Tensor:
     """Contiguous [128, 4] copy of weight[:, col0:col0+4] (the 4 meta columns of A2M.meta), cached."""
-    key = (weight.device.index, weight.data_ptr(), col0, "c4")
-    ver = weight._version
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
-    out = weight.detach()[:, col0:col0 + 4].contiguous()
-    _pack_cache[key] = (ver, out)
-    return out
+    return _cached(weight, ("c4", col0), lambda: _dev(weight.detach(), torch.float32, "weight")[:, col0:col0 + 4].contiguous())
 
 
-def clear_pack_cache():
-    _pack_cache.clear()
+# ------------------------------------------------------------------ per-kernel timing hook
+_timer = None
+
+
+class kernel_timer:
+    """``with ops.kernel_timer() as t:`` brackets every tagged launch with HIP events recorded on the
+    stream the kernel is launched on (torch's current stream); ``t.summary()`` -> {tag: [ms, ...]}.
+    Used by bench.py for the roofline of the dominant kernel; off (zero overhead) otherwise."""
+
+    def __enter__(self):
+        global _timer
+        self.recs = []
+        _timer = self
+        return self
+
+    def __exit__(self, *a):
+        global _timer
+        _timer = None
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for tag, e0, e1 in self.recs:
+            out.setdefault(tag, []).append(e0.elapsed_time(e1))
+        return out
+
+
+class _Timed:
+    def __init__(self, tag):
+        self.on = _timer is not None and tag is not None
+        self.tag = tag
+
+    def __enter__(self):
+        if self.on:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if self.on:
+            self.e1.record()
+            _timer.recs.append((self.tag, self.e0, self.e1))
 
 
 # ------------------------------------------------------------------ fp path
@@ -197,7 +243,7 @@ class RelSpec:
 
 
 def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, col=None, n_rel_csr=0,
-            gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, eps=EPS):
+            gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, eps=EPS, tag=None):
     """Fused aggregate -> GEMM -> GN -> ReLU -> GEMM -> GN -> +res -> ReLU row block (lgcn_agg_mlp)."""
     lib = L.load()
     if not rels or len(rels) > L.MAX_REL:
@@ -230,7 +276,8 @@ def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, co
         out = torch.empty((n_rows, C_FEAT), dtype=torch.float32, device=dev)
     p.out = out.data_ptr()
     p.out_pre = 0 if out_pre is None else out_pre.data_ptr()
-    L.check(lib.lgcn_agg_mlp(C.byref(p), _stream()), "lgcn_agg_mlp")
+    with _Timed(tag):
+        L.check(lib.lgcn_agg_mlp(C.byref(p), _stream()), "lgcn_agg_mlp")
     return out
 
 
@@ -246,12 +293,13 @@ def mapnet_input(ctrs, feats, wa1, ba1, wpa2, gn_a, ws1, bs1, wps2, gn_s, eps=EP
     return out
 
 
-def att_pairs(ps: PairSet, wd0, bd0, wpd2, gn_d, wpc0e, U, V, gn_c, m=None, eps=EPS):
+def att_pairs(ps: PairSet, wd0, bd0, wpd2, gn_d, wpc0e, U, V, gn_c, m=None, eps=EPS, tag="att_pairs"):
     lib = L.load()
     if m is None:
         m = torch.empty((max(ps.cap, 1), C_FEAT), dtype=torch.float32, device=U.device)
-    L.check(lib.lgcn_att_pairs(_ptr(ps.agt_ctrs), _ptr(ps.ctx_ctrs), _ptr(ps.hi), _ptr(ps.wi), _ptr(ps.n_pairs),
-                               ps.cap, _ptr(wd0), _ptr(bd0), _ptr(wpd2), _ptr(gn_d[0]), _ptr(gn_d[1]), _ptr(wpc0e),
-                               _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _ptr(m), _stream()),
-            "lgcn_att_pairs")
+    with _Timed(tag):
+        rc = lib.lgcn_att_pairs(_ptr(ps.agt_ctrs), _ptr(ps.ctx_ctrs), _ptr(ps.hi), _ptr(ps.wi), _ptr(ps.n_pairs),
+                                ps.cap, _ptr(wd0), _ptr(bd0), _ptr(wpd2), _ptr(gn_d[0]), _ptr(gn_d[1]), _ptr(wpc0e),
+                                _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _ptr(m), _stream())
+    L.check(rc, "lgcn_att_pairs")
     return m

@@ -307,3 +307,24 @@ def test_ragged_tail_tile(hip, ref_state_names):
     want = O.hot_path(O.graph_gather([sc["graph"]]), actors, [sc["ctrs"]], sd)
     for k in out:
         assert float(np.abs(out[k] - want[k].numpy()).max()) <= FTOL, k
+
+
+def test_full_net_forward_vs_reference(golden, ref_state_names, hip):
+    """Drop-in Net.forward(data) on the reference's batch format: cls / reg against the reference's own
+    output (ActorNet / PredNet are stock ATen; the hot path in between is HIP)."""
+    M, _ = hip
+    from lanegcn_amd import data as gen
+    scenes = load_scenes(golden)
+    net = M.Net(M.config)
+    net.load_state_dict(O.seeded_state(ref_state_names, int(golden["seed"])), strict=True)
+    net = net.cuda().eval()
+    batch = gen.collate_fn(scenes)
+    with torch.no_grad():
+        out = net(batch)
+    assert sorted(out.keys()) == ["cls", "reg"]
+    for i in range(len(scenes)):
+        cls, reg = out["cls"][i].cpu().numpy(), out["reg"][i].cpu().numpy()
+        assert cls.shape == golden["net/cls/%d" % i].shape and reg.shape == golden["net/reg/%d" % i].shape
+        assert float(np.abs(cls - golden["net/cls/%d" % i]).max()) <= 2e-4, i
+        # reg carries world coordinates up to ~1e3 m (scene 1 is offset by 1000 m): fp32 ulp there is 6e-5
+        assert np.allclose(reg, golden["net/reg/%d" % i], rtol=1e-6, atol=5e-4), i

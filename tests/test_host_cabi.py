@@ -1,0 +1,111 @@
+"""CPU: the C-ABI library loads, exports every symbol include/lgcn.h declares, and rejects bad
+arguments before launching anything (no compute calls: there is no GPU in the build container)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import _lib
+    return _lib.load(), _lib
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "lgcn.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lgcn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    l, mod = lib
+    names = header_symbols()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(l, n), "liblgcn.so does not export " + n
+    assert sorted(mod.SIGNATURES) == names, "ctypes binding and header disagree"
+
+
+def test_version_and_strerror(lib):
+    l, _ = lib
+    assert l.lgcn_version() == 100
+    assert l.lgcn_strerror(0) == b"ok"
+    assert b"invalid" in l.lgcn_strerror(-1)
+
+
+def test_struct_layout_matches_header(lib):
+    _, mod = lib
+    # lgcn_rel_t: 2 pointers + 2 int32; lgcn_agg_mlp_t: 24-byte head, 16 rels, 14 pointers
+    assert C.sizeof(mod.Rel) == 24
+    assert mod.AggMlp.rel.offset == 24
+    assert C.sizeof(mod.AggMlp) == 24 + 16 * 24 + 14 * 8
+
+
+def test_size_helpers(lib):
+    l, _ = lib
+    assert l.lgcn_csr_rowptr_elems(10368, 14) == 324 * 14 * 32 + 1
+    assert l.lgcn_csr_rowptr_elems(33, 14) == 2 * 14 * 32 + 1
+    assert l.lgcn_csr_rowptr_elems(10, 17) < 0
+    assert l.lgcn_csr_ws_elems(10368, 14) > l.lgcn_csr_rowptr_elems(10368, 14)
+    assert l.lgcn_pairs_ws_elems(1600, 32) >= 1601 + 64
+
+
+def test_bad_arguments_are_refused_without_launching(lib):
+    l, mod = lib
+    EINVAL, EALIGN = -1, -3
+    assert l.lgcn_graph_gather(None, 5, None, None, 1, None, None, None) == EINVAL
+    assert l.lgcn_graph_gather(None, 0, None, None, 0, None, None, None) == 0          # empty: nothing to do
+    assert l.lgcn_graph_gather(None, -1, None, None, 0, None, None, None) == EINVAL
+    assert l.lgcn_pack_weight(None, 128, 128, 128, None, None) == EINVAL
+    assert l.lgcn_pack_weight(C.c_void_p(64), 128, 128, 130, C.c_void_p(64), None) == EINVAL   # k_pad % 8
+    assert l.lgcn_pack_weight(C.c_void_p(64), 128, 128, 128, C.c_void_p(68), None) == EALIGN
+    p = mod.AggMlp()
+    assert l.lgcn_agg_mlp(None, None) == EINVAL
+    p.n_rows, p.n_rel = 10, 0
+    assert l.lgcn_agg_mlp(C.byref(p), None) == EINVAL
+    p.n_rel = 17
+    assert l.lgcn_agg_mlp(C.byref(p), None) == EINVAL
+    p.n_rows, p.n_rel = 0, 1
+    assert l.lgcn_agg_mlp(C.byref(p), None) == 0                                         # no rows: no launch
+    p.n_rows = 10
+    assert l.lgcn_agg_mlp(C.byref(p), None) == EINVAL                                    # null out / src
+    p.out = 256
+    p.rel[0].src, p.rel[0].wp, p.rel[0].mode = 256, 256, 7
+    assert l.lgcn_agg_mlp(C.byref(p), None) == EINVAL                                    # unknown mode
+    p.rel[0].mode = mod.REL_CSR
+    assert l.lgcn_agg_mlp(C.byref(p), None) == EINVAL                                    # ridx >= n_rel_csr
+    p.rel[0].mode, p.flags = mod.REL_IDENT, mod.F_GN2
+    assert l.lgcn_agg_mlp(C.byref(p), None) == EINVAL                                    # GN2 without GEMM2
+    p.flags = 0
+    p.rel[0].src = 260
+    assert l.lgcn_agg_mlp(C.byref(p), None) == EALIGN
+    assert l.lgcn_pairs_build(None, None, None, None, 0, 0, 0, 1.0, 1, None, None, 0, None, None, None, None) == EINVAL
+    assert l.lgcn_att_pairs(*([None] * 5), -1, *([None] * 10), 1e-5, None, None) == EINVAL
+    assert l.lgcn_att_pairs(*([None] * 5), 0, *([None] * 10), 1e-5, None, None) == 0
+    assert l.lgcn_mapnet_input(None, None, 5, *([None] * 10), 1e-5, None, None) == EINVAL
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "lanegcn-1_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("no oracle", ""), f + " mentions the oracle"
+
+
+def test_cpu_tensors_are_refused():
+    import torch
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import lanegcn as M
+    from lanegcn_amd._lib import LgcnError
+    m = M.M2M(M.config)
+    with torch.no_grad(), pytest.raises(LgcnError):
+        m(torch.zeros(4, 128), {})
+    with torch.no_grad(), pytest.raises(LgcnError):
+        M.Linear(128, 128, ng=1)(torch.zeros(4, 128))
