@@ -24,18 +24,23 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 C = 128
-PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# Dense matrix-core peaks (MI355X_MICROARCH.md).  The split mode spends 6 bf16 products per fp32-grade
+# multiply-add, so its effective peak in fp32-equivalent flops is the bf16 peak / 6.
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 6.0, "bf16": 2500.0}
+PEAK_NOTE = {"f32": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), 157.3 TF dense",
+             "bf16x3": "bf16 MFMA dense 2.5 PF / 6 products of the 3-way split (fp32-grade result)",
+             "bf16": "bf16 MFMA dense 2.5 PF"}
 PEAK_HBM_GBPS = 8000.0             # HBM3E spec
 
 
-def measured_traffic(workload):
+def measured_traffic(workload, mma):
     """HBM bytes per LaneConv launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their
     own runs, gfx950 corrections of MI355X_MICROARCH.md applied) committed under profiles/; None when
     no summary for this workload exists."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get(workload, {}).get("laneconv_hbm_bytes_per_launch")
+            return json.load(f).get("%s/%s" % (workload, mma), {}).get("laneconv_hbm_bytes_per_launch")
     except (OSError, ValueError):
         return None
 
@@ -126,6 +131,10 @@ def main():
     ap.add_argument("--scenes", type=int, default=None, help="override scenes per batch (S2: 32)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="forward graphs kept in flight on separate HIP streams (each on its own batch)")
+    ap.add_argument("--mma", default=None, choices=["f32", "bf16x3", "bf16"],
+                    help="matrix-core mode (default: LGCN_MMA or bf16x3 = fp32-grade 3-way bf16 split)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -147,6 +156,9 @@ def main():
         tdist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
     from lanegcn_amd.engine import HotPathEngine, collate_flat
 
+    if args.mma:
+        ops.set_mma(args.mma)
+    mma = ops.get_mma()
     mods = build_modules(1234, dev)            # same random-init weights on every rank
     scenes = gen.synth_batch(args.workload, seed=100 + rank, n_scenes=args.scenes)
     fb = collate_flat(scenes, dev)
@@ -160,9 +172,26 @@ def main():
         step = lambda: eng.forward(fb, actors)
         for _ in range(3):
             step()
-    else:
+    elif args.streams <= 1:
         graph, _ = eng.capture(fb, actors)
         step = graph.replay
+    else:
+        # S independent batches, one captured forward each, replayed round-robin on S streams: step k runs
+        # on stream k % S, so up to S forwards overlap on the GPU (every step is still a full batch-32 pass)
+        lanes = []
+        for j in range(args.streams):
+            sc = scenes if j == 0 else gen.synth_batch(args.workload, seed=100 + rank + 1000 * j, n_scenes=args.scenes)
+            fbj = fb if j == 0 else collate_flat(sc, dev)
+            aj = actors if j == 0 else torch.randn(fbj.n_actors, C, device=dev).relu()
+            gj, _ = eng.capture(fbj, aj)
+            lanes.append((torch.cuda.Stream(), gj))
+        counter = [0]
+
+        def step():
+            st, gj = lanes[counter[0] % len(lanes)]
+            counter[0] += 1
+            with torch.cuda.stream(st):
+                gj.replay()
 
     barrier = D.barrier
 
@@ -203,17 +232,21 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if mma == "bf16" else "f32", "mma": mma, "data": "synthetic",
             "config": {"workload": "%s: hot path forward (graph_gather+CSR plan+MapNet+A2M+M2M+M2A+A2A), "
                                    "%d scenes/GPU, %d lane nodes, %d edges, %d actors, random-init weights, "
                                    "inputs resident in HBM, %s" % (args.workload, n_scenes, fb.n_nodes, sum_e,
                                                                     fb.n_actors,
-                                                                    "eager" if args.no_graph else "hipGraph replay"),
+                                                                    "eager" if args.no_graph else "hipGraph replay" + (
+                                                                        "" if args.streams <= 1 else
+                                                                        ", %d forwards in flight on %d streams" % (args.streams, args.streams))),
                        "scenes_per_gpu": n_scenes, "parallelism": "dp%d (independent scene shards)" % args.gpus},
             "roofline": {
-                "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": measured_traffic(args.workload),
-                "kernel": "lgcn::k_agg_mlp<1> (fused LaneConv layer, 8 launches/step)",
+                "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[mma], "unit": "TFLOP/s",
+                "frac": ach / PEAK_TFLOPS[mma], "traffic": measured_traffic(args.workload, mma),
+                "peak_note": PEAK_NOTE[mma], "frac_of_f32_mfma_peak": ach / PEAK_TFLOPS["f32"],
+                "kernel": ("lgcn::k_agg_mlp<1>" if mma == "f32" else "lgcn::k_agg_mlp_bf<RB,NP,1>")
+                          + " (fused LaneConv layer, 8 launches/step)",
                 "avg_launch_us": lc_ms * 1e3, "algorithmic_flops_per_launch": flops,
                 "algorithmic_bytes_per_launch": byts,
                 "hbm_frac_algorithmic": byts / (lc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,

@@ -32,7 +32,7 @@ extern "C" {
 
 #define LGCN_VERSION 100       /* 0.1.0 */
 #define LGCN_C 128             /* n_map = n_actor = 128 (lanegcn.py:78-79) */
-#define LGCN_TM 32             /* rows of one MFMA tile / CSR tile */
+#define LGCN_TM 16             /* rows of one CSR sub-tile; kernel tiles are 1..4 sub-tiles */
 #define LGCN_MAX_REL 16        /* ctr + 14 lane relations (+1 spare) */
 
 enum {
@@ -67,8 +67,8 @@ int lgcn_graph_gather(const int64_t *in, int64_t n_elem,
  * -> tile-major CSR by destination.  Replaces the 14 index_add_ scatter
  * patterns of lanegcn.py:333-354 / 450-471 by an atomic-free gather.
  *
- *   key(n, r)   = ((n / 32) * n_rel + r) * 32 + n % 32
- *   rowptr      : [n_tiles * n_rel * 32 + 1] int32, n_tiles = ceil(n_nodes/32)
+ *   key(n, r)   = ((n / 16) * n_rel + r) * 16 + n % 16
+ *   rowptr      : [n_sub * n_rel * 16 + 1] int32, n_sub = ceil(n_nodes/16)
  *   col         : [sum_r n_edges[r]] int32, sources of row key in ascending
  *                 order of v (duplicates kept: index_add_ adds them twice)
  *
@@ -114,19 +114,36 @@ int lgcn_widen_i32(const int32_t *in, const int32_t *n_dev, int64_t cap,
                    int64_t *out, void *stream);
 
 /* ------------------------------------------------------------------ */
-/* Floating point path (fp32, f32-input MFMA; tolerance 1e-4 on features) */
+/* Floating point path (fp32 in / fp32 out; tolerance 1e-4 on features) */
 /* ------------------------------------------------------------------ */
 
 /*
- * Weight prepacking.  W is an nn.Linear weight [128, k_real] with row stride
- * ld (floats); the packed image feeds v_mfma_f32_32x32x2_f32 with one 16-byte
- * load per lane and 8 k-steps:
- *   out[w][q][lane][j] = W[32*w + (lane & 31)][8*q + 4*(lane >> 5) + j]
- * for w < 4, q < k_pad/8, j < 4 (zero for k >= k_real).  k_pad % 8 == 0.
- * out holds 128 * k_pad floats.
+ * How the 128-d Linear contractions are evaluated on the matrix cores:
+ *   LGCN_MMA_F32    v_mfma_f32_32x32x2_f32: bit-exact fp32 fma chain (64 FLOP/clk/SIMD).
+ *   LGCN_MMA_BF16X3 both operands split into 3 bf16 terms (x = hi + mid + lo, 24 mantissa
+ *                   bits), 6 products hi*hi, hi*mid, mid*hi, hi*lo, lo*hi, mid*mid on
+ *                   v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32-grade result
+ *                   (dropped terms <= 2^-24 relative) at 2.67x the f32 MFMA rate.
+ *   LGCN_MMA_BF16   one bf16 product (BASELINE config "bf16"; ~2e-2 relative on features).
  */
-int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad,
-                     float *out, void *stream);
+enum { LGCN_MMA_F32 = 0, LGCN_MMA_BF16X3 = 1, LGCN_MMA_BF16 = 2 };
+
+/*
+ * Weight prepacking.  W is an nn.Linear weight [128, k_real] with row stride
+ * ld (floats).
+ * LGCN_MMA_F32: the image feeds v_mfma_f32_32x32x2_f32 with one 16-byte load
+ * per lane per 8 k's:
+ *   out[w][q][lane][j] = W[32*w + (lane & 31)][8*q + 4*(lane >> 5) + j]   (fp32)
+ * for w < 4, q < k_pad/8, j < 4 (zero for k >= k_real), k_pad % 8 == 0;
+ * out holds 128 * k_pad floats.
+ * LGCN_MMA_BF16X3 / LGCN_MMA_BF16: k_real = k_pad = 128; 3 (1) bf16 planes
+ * (hi, mid, lo of the 3-way split) for v_mfma_f32_16x16x32_bf16:
+ *   out[p][w][s][cb][lane][j] = plane_p(W[32*w + 16*cb + (lane & 15)][32*s + 8*(lane >> 4) + j])
+ * p < planes, w < 4, s < 4, cb < 2, j < 8; out holds planes * 32 KiB.
+ */
+int64_t lgcn_packed_bytes(int k_pad, int mma);
+int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad, int mma,
+                     void *out, void *stream);
 
 /* One relation of an aggregate-GEMM stage (see lgcn_agg_mlp). */
 typedef struct {
@@ -153,6 +170,8 @@ typedef struct {
     int32_t n_rel_csr;       /* relations in the CSR plan (rowptr layout)  */
     int32_t flags;           /* LGCN_F_*                                   */
     float eps;               /* GroupNorm eps (1e-5)                       */
+    int32_t mma;             /* LGCN_MMA_* (all wp / wp2 packed for it)    */
+    int32_t tile_rb;         /* bf16 modes: 16-row blocks per tile, 1..4; 0 = pick by occupancy */
     lgcn_rel_t rel[LGCN_MAX_REL];
     const int32_t *rowptr;   /* CSR plan rowptr, or [N+1] for RANGE        */
     const int32_t *col;      /* CSR plan col                               */
@@ -190,7 +209,7 @@ int lgcn_mapnet_input(const float *ctrs, const float *feats, int64_t n_rows,
                       const float *ga, const float *bta,
                       const float *ws1, const float *bs1, const float *wps2,
                       const float *gs, const float *bts,
-                      float eps, float *out, void *stream);
+                      float eps, int mma, float *out, void *stream);
 
 /*
  * Att.forward per-pair MLP, lanegcn.py:691-700, for pairs p < *n_pairs:
@@ -210,7 +229,7 @@ int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs,
                    const float *gd, const float *btd,
                    const float *wpc0e, const float *U, const float *V,
                    const float *gc, const float *btc,
-                   float eps, float *m, void *stream);
+                   float eps, int mma, float *m, void *stream);
 
 #ifdef __cplusplus
 }

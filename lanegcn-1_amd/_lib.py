@@ -8,6 +8,8 @@ LIB_PATH = os.path.join(_HERE, "liblgcn.so")
 MAX_REL = 16
 REL_IDENT, REL_CSR, REL_RANGE = 0, 1, 2
 F_GN1, F_RELU1, F_GEMM2, F_GN2, F_RES, F_RELU2 = 1, 2, 4, 8, 16, 32
+MMA_F32, MMA_BF16X3, MMA_BF16 = 0, 1, 2
+MMA_NAMES = {"f32": MMA_F32, "bf16x3": MMA_BF16X3, "bf16": MMA_BF16}
 
 
 class LgcnError(RuntimeError):
@@ -21,7 +23,7 @@ class Rel(C.Structure):
 class AggMlp(C.Structure):
     _fields_ = [
         ("n_rows", C.c_int64), ("n_rel", C.c_int32), ("n_rel_csr", C.c_int32),
-        ("flags", C.c_int32), ("eps", C.c_float),
+        ("flags", C.c_int32), ("eps", C.c_float), ("mma", C.c_int32), ("tile_rb", C.c_int32),
         ("rel", Rel * MAX_REL),
         ("rowptr", C.c_void_p), ("col", C.c_void_p),
         ("x4_a", C.c_void_p), ("x4_b", C.c_void_p), ("x4_c", C.c_void_p), ("w4", C.c_void_p),
@@ -44,10 +46,11 @@ SIGNATURES = {
     "lgcn_pairs_ws_elems": (C.c_int64, [_L, _I]),
     "lgcn_pairs_build": (C.c_int, [_P, _P, _P, _P, _I, _L, _L, _F, _I, _P, _P, _L, _P, _P, _P, _P]),
     "lgcn_widen_i32": (C.c_int, [_P, _P, _L, _P, _P]),
-    "lgcn_pack_weight": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "lgcn_packed_bytes": (C.c_int64, [_I, _I]),
+    "lgcn_pack_weight": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "lgcn_agg_mlp": (C.c_int, [C.POINTER(AggMlp), _P]),
-    "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _P, _P]),
-    "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _P, _P]),
+    "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
+    "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
 }
 
 _lib = None

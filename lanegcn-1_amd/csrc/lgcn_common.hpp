@@ -7,7 +7,7 @@
 namespace lgcn {
 
 constexpr int kC = LGCN_C;          // channels
-constexpr int kTM = LGCN_TM;        // rows per tile
+constexpr int kSub = LGCN_TM;       // rows of one CSR sub-tile (16)
 constexpr int kLDA = kC + 4;        // padded LDS row stride (floats): 528 B rows,
                                     // conflict-free for ds_read_b128 over 16 rows
 constexpr int kWave = 64;

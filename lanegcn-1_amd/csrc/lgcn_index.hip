@@ -129,7 +129,7 @@ struct CooTable {
 };
 
 __device__ __forceinline__ int64_t csr_key(int64_t n, int r, int n_rel) {
-    return ((n >> 5) * n_rel + r) * 32 + (n & 31);
+    return ((n >> 4) * n_rel + r) * 16 + (n & 15);
 }
 
 // pass 0: count, pass 1: fill
@@ -317,7 +317,7 @@ int lgcn_graph_gather(const int64_t *in, int64_t n_elem, const int64_t *seg_off,
 
 int64_t lgcn_csr_rowptr_elems(int64_t n_nodes, int n_rel) {
     if (n_nodes < 0 || n_rel < 1 || n_rel > LGCN_MAX_REL) return LGCN_EINVAL;
-    return ((n_nodes + 31) / 32) * n_rel * 32 + 1;
+    return ((n_nodes + 15) / 16) * n_rel * 16 + 1;
 }
 
 int64_t lgcn_csr_ws_elems(int64_t n_nodes, int n_rel) {

@@ -8,10 +8,12 @@
 // weight straight from L2 to registers (no wave shares a weight element);
 // the A operand (gathered rows) is the shared, LDS-resident one.
 #include "lgcn_common.hpp"
+#include "lgcn_tile.hpp"
 
 namespace lgcn {
 
-constexpr int kTileFloats = kTM * kLDA;  // one 32 x (128+4) LDS tile
+constexpr int kTM32 = 32;                  // rows of one f32-MFMA tile (two CSR sub-tiles)
+constexpr int kTileFloats = kTM32 * kLDA;  // one 32 x (128+4) LDS tile
 
 // acc[32 x 32 block of this wave] += A[32 x 8*nq] * Wpacked
 // A operand of 32x32x2: lane l holds A[l & 31][k = l >> 5]; B operand holds
@@ -41,84 +43,6 @@ __device__ __forceinline__ void acc_to_lds(float *T, const f32x16 &acc, int lane
     for (int i = 0; i < 16; ++i) p[acc_row(i, lane) * kLDA] = acc[i];
 }
 
-// Row phase: thread (row = t >> 3, sub = t & 7) of the 256 compute threads
-// owns columns 4*sub + 32*j + {0..3}, j = 0..3 of its row (8 threads write
-// 128 contiguous bytes per j when the row goes to global memory).
-struct RowVals { float4 v[4]; };
-
-__device__ __forceinline__ RowVals row_load(const float *T, int t) {
-    RowVals r;
-    const float *p = T + (t >> 3) * kLDA + 4 * (t & 7);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) r.v[j] = *reinterpret_cast<const float4 *>(p + 32 * j);
-    return r;
-}
-
-__device__ __forceinline__ void row_store_lds(float *T, int t, const RowVals &r) {
-    float *p = T + (t >> 3) * kLDA + 4 * (t & 7);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(p + 32 * j) = r.v[j];
-}
-
-__device__ __forceinline__ float sum8(float x) {  // over the 8 lanes that share a row
-    x += __shfl_xor(x, 1, 64);
-    x += __shfl_xor(x, 2, 64);
-    x += __shfl_xor(x, 4, 64);
-    return x;
-}
-
-// GroupNorm(1, 128): per-row mean / biased variance over the 128 channels
-// (layers.py:73, gcd(1, n_out) = 1 group), two-pass in registers.
-__device__ __forceinline__ void row_gn(RowVals &r, int t, const float *__restrict__ g,
-                                       const float *__restrict__ b, float eps) {
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) s += (r.v[j].x + r.v[j].y) + (r.v[j].z + r.v[j].w);
-    const float mean = sum8(s) * (1.0f / kC);
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float a = r.v[j].x - mean, bb = r.v[j].y - mean, c = r.v[j].z - mean, d = r.v[j].w - mean;
-        q += (a * a + bb * bb) + (c * c + d * d);
-    }
-    const float rstd = 1.0f / sqrtf(sum8(q) * (1.0f / kC) + eps);
-    const int c0 = 4 * (t & 7);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4 gg = *reinterpret_cast<const float4 *>(g + c0 + 32 * j);
-        const float4 bb = *reinterpret_cast<const float4 *>(b + c0 + 32 * j);
-        r.v[j].x = (r.v[j].x - mean) * rstd * gg.x + bb.x;
-        r.v[j].y = (r.v[j].y - mean) * rstd * gg.y + bb.y;
-        r.v[j].z = (r.v[j].z - mean) * rstd * gg.z + bb.z;
-        r.v[j].w = (r.v[j].w - mean) * rstd * gg.w + bb.w;
-    }
-}
-
-__device__ __forceinline__ void row_relu(RowVals &r) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        r.v[j].x = fmaxf(r.v[j].x, 0.f); r.v[j].y = fmaxf(r.v[j].y, 0.f);
-        r.v[j].z = fmaxf(r.v[j].z, 0.f); r.v[j].w = fmaxf(r.v[j].w, 0.f);
-    }
-}
-
-__device__ __forceinline__ void row_add_global(RowVals &r, const float *__restrict__ rowp, int t) {
-    const float *p = rowp + 4 * (t & 7);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4 x = *reinterpret_cast<const float4 *>(p + 32 * j);
-        r.v[j].x += x.x; r.v[j].y += x.y; r.v[j].z += x.z; r.v[j].w += x.w;
-    }
-}
-
-__device__ __forceinline__ void row_store_global(float *__restrict__ rowp, int t, const RowVals &r) {
-    float *p = rowp + 4 * (t & 7);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(p + 32 * j) = r.v[j];
-}
-
-__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
-
 // ------------------------------------------------------------ packing -----
 __global__ __launch_bounds__(256) void k_pack_weight(const float *__restrict__ W, int ld, int k_real, int k_pad,
                                                      float *__restrict__ out) {
@@ -143,11 +67,11 @@ __device__ __forceinline__ void gather_rel(float *__restrict__ Abuf, const lgcn_
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int row = it * 8 + hw;
-        const int64_t n = (int64_t)tile * kTM + row;
+        const int64_t n = (int64_t)tile * kTM32 + row;
         b[it] = 0; e[it] = 0;
         if (n < p.n_rows) {
-            if (mode == LGCN_REL_CSR) {
-                const int64_t k = ((int64_t)tile * p.n_rel_csr + p.rel[ri].ridx) * 32 + row;
+            if (mode == LGCN_REL_CSR) {   // 32-row tile = CSR sub-tiles 2*tile, 2*tile+1
+                const int64_t k = (((int64_t)tile * 2 + (row >> 4)) * p.n_rel_csr + p.rel[ri].ridx) * 16 + (row & 15);
                 b[it] = p.rowptr[k]; e[it] = p.rowptr[k + 1];
             } else if (mode == LGCN_REL_RANGE) {
                 b[it] = p.rowptr[n]; e[it] = p.rowptr[n + 1];
@@ -194,7 +118,7 @@ __global__ __launch_bounds__(512) void k_agg_mlp(const lgcn_agg_mlp_t p, int n_t
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_chunk_remap(blockIdx.x, n_tiles);
-    const int64_t row0 = (int64_t)tile * kTM;
+    const int64_t row0 = (int64_t)tile * kTM32;
 
     // active relations of this tile (a relation with no edge into the tile
     // contributes an all-zero A tile: skip its gather and its MFMAs)
@@ -203,10 +127,16 @@ __global__ __launch_bounds__(512) void k_agg_mlp(const lgcn_agg_mlp_t p, int n_t
         if (lane < p.n_rel) {
             const int mode = p.rel[lane].mode;
             if (mode == LGCN_REL_CSR) {
-                const int64_t k0 = ((int64_t)tile * p.n_rel_csr + p.rel[lane].ridx) * 32;
-                on = p.rowptr[k0 + 32] > p.rowptr[k0];
+                const int64_t n_sub = (p.n_rows + 15) >> 4;
+                for (int h = 0; h < 2; ++h) {
+                    const int64_t sub = (int64_t)tile * 2 + h;
+                    if (sub < n_sub) {
+                        const int64_t k0 = (sub * p.n_rel_csr + p.rel[lane].ridx) * 16;
+                        on = on || p.rowptr[k0 + 16] > p.rowptr[k0];
+                    }
+                }
             } else if (mode == LGCN_REL_RANGE) {
-                const int64_t r1 = row0 + kTM < p.n_rows ? row0 + kTM : p.n_rows;
+                const int64_t r1 = row0 + kTM32 < p.n_rows ? row0 + kTM32 : p.n_rows;
                 on = p.rowptr[r1] > p.rowptr[row0];
             } else {
                 on = true;
@@ -317,21 +247,12 @@ __device__ __forceinline__ void lin2_relu_to_lds(float *T, int t, float x, float
     }
 }
 
-struct InputParams {
-    const float *ctrs, *feats;
-    int64_t n_rows;
-    const float *wa1, *ba1, *wpa2, *ga, *bta;
-    const float *ws1, *bs1, *wps2, *gs, *bts;
-    float eps;
-    float *out;
-};
-
 __global__ __launch_bounds__(256) void k_mapnet_input(const InputParams p, int n_tiles) {
     __shared__ __attribute__((aligned(16))) float smem[2 * kTileFloats];
     float *T1 = smem, *T2 = smem + kTileFloats;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = blockIdx.x;
-    const int64_t n = (int64_t)tile * kTM + (tid >> 3);
+    const int64_t n = (int64_t)tile * kTM32 + (tid >> 3);
     const bool live = n < p.n_rows;
     f32x16 acc;
 
@@ -364,27 +285,17 @@ __global__ __launch_bounds__(256) void k_mapnet_input(const InputParams p, int n
 }
 
 // ---------------------------------------------------------- att pairs -----
-struct PairParams {
-    const float *agt_ctrs, *ctx_ctrs;
-    const int32_t *hi, *wi, *n_pairs;
-    int64_t cap;
-    const float *wd0, *bd0, *wpd2, *gd, *btd;
-    const float *wpc0e, *U, *V, *gc, *btc;
-    float eps;
-    float *m;
-};
-
 __global__ __launch_bounds__(256) void k_att_pairs(const PairParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * kTileFloats];
     float *T1 = smem, *T2 = smem + kTileFloats;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int64_t P = *p.n_pairs;
     if (P < 0 || P > p.cap) P = p.cap;
-    const int64_t n_tiles = (P + kTM - 1) / kTM;
+    const int64_t n_tiles = (P + kTM32 - 1) / kTM32;
     f32x16 acc;
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const int64_t pr = tile * kTM + (tid >> 3);
+        const int64_t pr = tile * kTM32 + (tid >> 3);
         const bool live = pr < P;
         int h = 0, w = 0;
         float dx = 0.f, dy = 0.f;
@@ -434,19 +345,33 @@ using namespace lgcn;
 
 extern "C" {
 
-int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad, float *out, void *stream) {
+static bool valid_mma(int mma) { return mma == LGCN_MMA_F32 || mma == LGCN_MMA_BF16X3 || mma == LGCN_MMA_BF16; }
+
+int64_t lgcn_packed_bytes(int k_pad, int mma) {
+    if (!valid_mma(mma) || k_pad < 8 || (k_pad & 7)) return LGCN_EINVAL;
+    if (mma == LGCN_MMA_F32) return (int64_t)kC * k_pad * 4;
+    if (k_pad != kC) return LGCN_ESHAPE;
+    return (int64_t)(mma == LGCN_MMA_BF16X3 ? 3 : 1) * kC * kC * 2;
+}
+
+int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad, int mma, void *out, void *stream) {
     LGCN_CHECK_PTR(W); LGCN_CHECK_PTR(out);
-    if (k_real < 1 || k_pad < k_real || (k_pad & 7) || ld < k_real) return LGCN_EINVAL;
+    if (!valid_mma(mma) || k_real < 1 || k_pad < k_real || (k_pad & 7) || ld < k_real) return LGCN_EINVAL;
     LGCN_CHECK_ALIGN16(out);
+    if (mma != LGCN_MMA_F32) {
+        if (k_real != kC || k_pad != kC) return LGCN_ESHAPE;
+        return pack_weight_bf(W, ld, mma == LGCN_MMA_BF16X3 ? 3 : 1, out, (hipStream_t)stream);
+    }
     const int total = kC * k_pad;
-    hipLaunchKernelGGL(k_pack_weight, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, ld, k_real, k_pad, out);
+    hipLaunchKernelGGL(k_pack_weight, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, ld, k_real, k_pad,
+                       reinterpret_cast<float *>(out));
     return launch_status();
 }
 
 int lgcn_agg_mlp(const lgcn_agg_mlp_t *ph, void *stream) {
     LGCN_CHECK_PTR(ph);
     const lgcn_agg_mlp_t &p = *ph;
-    if (p.n_rows < 0 || p.n_rel < 1 || p.n_rel > LGCN_MAX_REL) return LGCN_EINVAL;
+    if (p.n_rows < 0 || p.n_rel < 1 || p.n_rel > LGCN_MAX_REL || !valid_mma(p.mma)) return LGCN_EINVAL;
     if (p.n_rows == 0) return LGCN_OK;
     if (p.n_rows > 0x7fffffff) return LGCN_ESHAPE;
     LGCN_CHECK_PTR(p.out); LGCN_CHECK_ALIGN16(p.out);
@@ -475,7 +400,8 @@ int lgcn_agg_mlp(const lgcn_agg_mlp_t *ph, void *stream) {
     if (p.flags & LGCN_F_RES) { LGCN_CHECK_PTR(p.res); LGCN_CHECK_ALIGN16(p.res); }
     if (p.w4) { LGCN_CHECK_PTR(p.x4_a); LGCN_CHECK_PTR(p.x4_b); LGCN_CHECK_PTR(p.x4_c); LGCN_CHECK_ALIGN16(p.w4); }
     if (p.out_pre) LGCN_CHECK_ALIGN16(p.out_pre);
-    const int n_tiles = (int)((p.n_rows + kTM - 1) / kTM);
+    if (p.mma != LGCN_MMA_F32) return agg_mlp_bf(p, need_col, (hipStream_t)stream);
+    const int n_tiles = (int)((p.n_rows + kTM32 - 1) / kTM32);
     if (need_col)
         hipLaunchKernelGGL((k_agg_mlp<1>), dim3(n_tiles), dim3(512), 0, (hipStream_t)stream, p, n_tiles);
     else
@@ -485,8 +411,8 @@ int lgcn_agg_mlp(const lgcn_agg_mlp_t *ph, void *stream) {
 
 int lgcn_mapnet_input(const float *ctrs, const float *feats, int64_t n_rows, const float *wa1, const float *ba1,
                       const float *wpa2, const float *ga, const float *bta, const float *ws1, const float *bs1,
-                      const float *wps2, const float *gs, const float *bts, float eps, float *out, void *stream) {
-    if (n_rows < 0) return LGCN_EINVAL;
+                      const float *wps2, const float *gs, const float *bts, float eps, int mma, float *out, void *stream) {
+    if (n_rows < 0 || !valid_mma(mma)) return LGCN_EINVAL;
     if (n_rows == 0) return LGCN_OK;
     if (n_rows > 0x7fffffff) return LGCN_ESHAPE;
     const void *ptrs[] = {ctrs, feats, wa1, ba1, wpa2, ga, bta, ws1, bs1, wps2, gs, bts, out};
@@ -494,7 +420,8 @@ int lgcn_mapnet_input(const float *ctrs, const float *feats, int64_t n_rows, con
     const void *al[] = {wa1, ba1, wpa2, ga, bta, ws1, bs1, wps2, gs, bts, out};
     for (const void *q : al) LGCN_CHECK_ALIGN16(q);
     InputParams p{ctrs, feats, n_rows, wa1, ba1, wpa2, ga, bta, ws1, bs1, wps2, gs, bts, eps, out};
-    const int n_tiles = (int)((n_rows + kTM - 1) / kTM);
+    if (mma != LGCN_MMA_F32) return mapnet_input_bf(p, mma, (hipStream_t)stream);
+    const int n_tiles = (int)((n_rows + kTM32 - 1) / kTM32);
     hipLaunchKernelGGL(k_mapnet_input, dim3(n_tiles), dim3(256), 0, (hipStream_t)stream, p, n_tiles);
     return launch_status();
 }
@@ -502,8 +429,8 @@ int lgcn_mapnet_input(const float *ctrs, const float *feats, int64_t n_rows, con
 int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs, const int32_t *hi, const int32_t *wi,
                    const int32_t *n_pairs, int64_t cap, const float *wd0, const float *bd0, const float *wpd2,
                    const float *gd, const float *btd, const float *wpc0e, const float *U, const float *V,
-                   const float *gc, const float *btc, float eps, float *m, void *stream) {
-    if (cap < 0) return LGCN_EINVAL;
+                   const float *gc, const float *btc, float eps, int mma, float *m, void *stream) {
+    if (cap < 0 || !valid_mma(mma)) return LGCN_EINVAL;
     if (cap == 0) return LGCN_OK;
     if (cap > 0x7ffffff0) return LGCN_ESHAPE;
     const void *ptrs[] = {agt_ctrs, ctx_ctrs, hi, wi, n_pairs, wd0, bd0, wpd2, gd, btd, wpc0e, U, V, gc, btc, m};
@@ -511,7 +438,8 @@ int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs, const int32_t *
     const void *al[] = {wd0, bd0, wpd2, gd, btd, wpc0e, U, V, gc, btc, m};
     for (const void *q : al) LGCN_CHECK_ALIGN16(q);
     PairParams p{agt_ctrs, ctx_ctrs, hi, wi, n_pairs, cap, wd0, bd0, wpd2, gd, btd, wpc0e, U, V, gc, btc, eps, m};
-    int64_t tiles = (cap + kTM - 1) / kTM;
+    if (mma != LGCN_MMA_F32) return att_pairs_bf(p, mma, (hipStream_t)stream);
+    int64_t tiles = (cap + kTM32 - 1) / kTM32;
     const unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
     hipLaunchKernelGGL(k_att_pairs, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     return launch_status();

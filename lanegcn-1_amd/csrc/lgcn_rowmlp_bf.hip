@@ -1,0 +1,687 @@
+// Split-bf16 variant of the row-block kernels (LGCN_MMA_BF16X3 / LGCN_MMA_BF16).
+//
+// fp32 operands are split into NP bf16 planes (x = hi + mid + lo, 3 x 8 mantissa
+// bits); a K = 128 pass contracts the planes pairwise on
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation:
+//   NP = 3: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi  (dropped terms <= 2^-24)
+//   NP = 1: hi*hi
+// Tile = 16*RB rows (RB = 1..4 CSR sub-tiles, picked per launch so that the tile
+// count fits the 256 CUs in as few rounds as possible) x 128 output channels;
+// wave w of the 4 MFMA waves owns channels [32w, 32w+32) as two 16-column
+// blocks and streams its own packed weight slice L2 -> VGPR; the A planes live
+// in LDS (272-byte rows: conflict-free ds_read_b128), double-buffered against
+// the 4 gather waves exactly like the f32 kernel.
+#include "lgcn_common.hpp"
+#include "lgcn_tile.hpp"
+
+namespace lgcn {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kLDB = kC + 8;  // bf16 elements per LDS plane row (272 B)
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// Split 4 consecutive channels of one row into NP planes and store them.
+template <int NP>
+__device__ __forceinline__ void split_store(uint16_t *planes, int plane_elems, int row, int col, float4 v) {
+    uint16_t *dst = planes + row * kLDB + col;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
+        *reinterpret_cast<uint2 *>(dst + p * plane_elems) = make_uint2(a, b);
+        if (p + 1 < NP) {  // residual is exact in fp32
+            v.x -= bf16_lo(a); v.y -= bf16_hi(a); v.z -= bf16_lo(b); v.w -= bf16_hi(b);
+        }
+    }
+}
+
+template <int RB, int NP>
+struct Tile {
+    static constexpr int ROWS = 16 * RB;
+    static constexpr int PLANE = ROWS * kLDB;            // bf16 elements
+    static constexpr int ABUF_BYTES = NP * PLANE * 2;    // one set of planes
+    static constexpr int T_BYTES = ROWS * kLDA * 4;      // fp32 epilogue tile
+    static constexpr int SMEM = (2 * ABUF_BYTES > T_BYTES + ABUF_BYTES ? 2 * ABUF_BYTES : T_BYTES + ABUF_BYTES);
+};
+
+// acc[rb][cb] (16 x 16 blocks: rows 16rb.., channels 32w + 16cb..) += A(planes) * W
+// A operand of 16x16x32: lane l holds A[l & 15][k = 8 (l >> 4) + j]; B operand B[k][col = l & 15].
+template <int NP>
+struct BFrag { bf16x8 v[NP][2]; };
+
+template <int NP>
+__device__ __forceinline__ void load_b(BFrag<NP> &b, const uint4 *__restrict__ Bw, int wave, int lane, int s) {
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+            b.v[p][cb] = __builtin_bit_cast(bf16x8, Bw[((((p * 4 + wave) * 4 + s) * 2 + cb) << 6) + lane]);
+}
+
+template <int RB, int NP>
+__device__ __forceinline__ void kstep(const uint16_t *__restrict__ arow, int s, const BFrag<NP> &b, f32x4 (&acc)[RB][2]) {
+    constexpr int PLANE = Tile<RB, NP>::PLANE;
+    bf16x8 a[NP][RB];
+#pragma unroll
+    for (int p = 0; p < NP; ++p)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            a[p][rb] = *reinterpret_cast<const bf16x8 *>(arow + p * PLANE + rb * 16 * kLDB + 32 * s);
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x4 c = acc[rb][cb];
+            if (NP == 3) {  // small terms first
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2][rb], b.v[0][cb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b.v[2][cb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][rb], b.v[1][cb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][rb], b.v[0][cb], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b.v[1][cb], c, 0, 0, 0);
+            }
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b.v[0][cb], c, 0, 0, 0);
+            acc[rb][cb] = c;
+        }
+}
+
+// Weight-fragment ring: 4 sets = the 4 K-steps of a pass, prefetch distance 3 K-steps.  On entry
+// ring.b[0..2] hold K-steps 0..2 of Bw; step s first issues the load of the step 3 ahead (K-step 3 of
+// this pass for s = 0, K-step s-1 of Bw_next for s >= 1) and then runs its MFMAs, so a fragment has
+// three K-steps of MFMA time to arrive and the stream stays ahead across the per-relation barrier.
+template <int NP>
+struct BRing { BFrag<NP> b[4]; };
+
+template <int NP>
+__device__ __forceinline__ void ring_prime(BRing<NP> &r, const uint4 *__restrict__ Bw, int wave, int lane) {
+    load_b<NP>(r.b[0], Bw, wave, lane, 0);
+    load_b<NP>(r.b[1], Bw, wave, lane, 1);
+    load_b<NP>(r.b[2], Bw, wave, lane, 2);
+}
+
+template <int RB, int NP>
+__device__ __forceinline__ void gemm_pass(const uint16_t *__restrict__ A, const uint4 *__restrict__ Bw,
+                                          const uint4 *__restrict__ Bw_next, BRing<NP> &r, int wave, int lane,
+                                          f32x4 (&acc)[RB][2]) {
+    const uint16_t *arow = A + (lane & 15) * kLDB + 8 * (lane >> 4);
+    load_b<NP>(r.b[3], Bw, wave, lane, 3);
+    kstep<RB, NP>(arow, 0, r.b[0], acc);
+    if (Bw_next != nullptr) load_b<NP>(r.b[0], Bw_next, wave, lane, 0);
+    kstep<RB, NP>(arow, 1, r.b[1], acc);
+    if (Bw_next != nullptr) load_b<NP>(r.b[1], Bw_next, wave, lane, 1);
+    kstep<RB, NP>(arow, 2, r.b[2], acc);
+    if (Bw_next != nullptr) load_b<NP>(r.b[2], Bw_next, wave, lane, 2);
+    kstep<RB, NP>(arow, 3, r.b[3], acc);
+}
+
+// C/D layout of 16x16: col = lane & 15, row = 4 (lane >> 4) + reg
+template <int RB>
+__device__ __forceinline__ void acc_store(float *T, const f32x4 (&acc)[RB][2], int lane, int wave) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            float *p = T + (16 * rb + 4 * (lane >> 4)) * kLDA + 32 * wave + 16 * cb + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) p[i * kLDA] = acc[rb][cb][i];
+        }
+}
+
+template <int RB>
+__device__ __forceinline__ void acc_zero(f32x4 (&acc)[RB][2]) {
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int NP>
+__device__ __forceinline__ void row_split_store(uint16_t *planes, int plane_elems, int row, int t, const RowVals &r) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split_store<NP>(planes, plane_elems, row, 4 * (t & 7) + 32 * j, r.v[j]);
+}
+
+// ------------------------------------------------------------ packing -----
+__global__ __launch_bounds__(256) void k_pack_weight_bf(const float *__restrict__ W, int ld, int n_planes,
+                                                        uint16_t *__restrict__ out) {
+    // one thread per (w, s, cb, lane): 8 consecutive k of one weight row -> 8 bf16 per plane
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * 4 * 2 * 64) return;
+    const int lane = i & 63, cb = (i >> 6) & 1, s = (i >> 7) & 3, w = i >> 9;
+    const float *src = W + (int64_t)(32 * w + 16 * cb + (lane & 15)) * ld + 32 * s + 8 * (lane >> 4);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[j];
+    for (int p = 0; p < n_planes; ++p) {
+        uint32_t q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            q[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+            v[2 * j] -= bf16_lo(q[j]);
+            v[2 * j + 1] -= bf16_hi(q[j]);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(out) + ((((p * 4 + w) * 4 + s) * 2 + cb) << 6) + lane;
+        *dst = make_uint4(q[0], q[1], q[2], q[3]);
+    }
+}
+
+// ------------------------------------------------------------ agg_mlp -----
+// Per-tile index slice, loaded into LDS once: the rowptr chunk of every CSR sub-tile (n_rel_csr*16+1
+// ints each, contiguous in the tile-major plan), the col entries they span, and rowptr[row0..row0+ROWS]
+// for the RANGE relation.  A gather then needs ONE dependent global access (the source row) per pass
+// instead of three (rowptr -> col -> row).
+template <int RB>
+struct TileIdx {
+    static constexpr int RP = LGCN_MAX_REL * 16 + 4;   // ints per sub-tile chunk (<= 16*16+1)
+    static constexpr int COLCAP = 64 * 16 * RB;        // col entries kept in LDS (fallback: global)
+    static constexpr int INTS = RB * RP + COLCAP + 16 * RB + 4 + 2 * RB + 4;
+    int *rp;      // [RB][RP]
+    int *col;     // [COLCAP]
+    int *rng;     // [16*RB + 1]
+    int *c0;      // [RB] first col entry of the sub-tile (global index)
+    int *lo;      // [RB] offset of the sub-tile's entries in `col`;  lo[RB] (stored at c0[-1]..) unused
+    int *flag;    // [0] = 1 when col[] holds the tile's entries
+    __device__ explicit TileIdx(int *base) {
+        rp = base; col = rp + RB * RP; rng = col + COLCAP; c0 = rng + 16 * RB + 4; lo = c0 + RB; flag = lo + RB;
+    }
+};
+
+// A gather is split in two so that two relations can be in flight per gather wave:
+//   gather_issue : row bounds from LDS, then the FIRST source row of each of the wave's destination rows
+//                  as unconditional loads (index clamped to row 0 when a row has no source), so the
+//                  compiler can count them and a later finish of the OTHER register set does not drain them;
+//   gather_finish: remaining sources (rows with > 1 edge), bf16 split, LDS planes.
+template <int RB>
+struct GReg {
+    static constexpr int IT = 2 * RB;   // 8 destination rows per sweep (one half-wave per row)
+    float4 s[IT];
+    int b[IT], e[IT], cadj[IT];
+};
+
+template <int RB>
+__device__ __forceinline__ int gather_source(const lgcn_agg_mlp_t &p, const TileIdx<RB> &ix, int mode, bool lds_col,
+                                             int cadj, int j) {
+    if (mode != LGCN_REL_CSR) return j;
+    return lds_col ? ix.col[j + cadj] : p.col[j];
+}
+
+template <int RB>
+__device__ __forceinline__ void gather_issue(GReg<RB> &g, const lgcn_agg_mlp_t &p, int ri, int tile, int gt,
+                                             const TileIdx<RB> &ix) {
+    constexpr int IT = GReg<RB>::IT;
+    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(p.rel[ri].src);
+    const int mode = p.rel[ri].mode, ridx = p.rel[ri].ridx;
+    const int hw = gt >> 5, l = gt & 31;
+    const bool lds_col = ix.flag[0] != 0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int row = it * 8 + hw;
+        const int64_t n = (int64_t)tile * (16 * RB) + row;
+        int b = 0, e = 0, cadj = 0;
+        if (n < p.n_rows) {
+            if (mode == LGCN_REL_CSR) {
+                const int rb = row >> 4;
+                b = ix.rp[rb * TileIdx<RB>::RP + ridx * 16 + (row & 15)];
+                e = ix.rp[rb * TileIdx<RB>::RP + ridx * 16 + (row & 15) + 1];
+                cadj = ix.lo[rb] - ix.c0[rb];      // global col index -> LDS col index
+            } else if (mode == LGCN_REL_RANGE) {
+                b = ix.rng[row]; e = ix.rng[row + 1];
+            } else {
+                b = (int)n; e = (int)n + 1;
+            }
+        }
+        g.b[it] = b; g.e[it] = e; g.cadj[it] = cadj;
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int idx = g.b[it] < g.e[it] ? gather_source<RB>(p, ix, mode, lds_col, g.cadj[it], g.b[it]) : 0;
+        g.s[it] = src[(int64_t)idx * 32 + l];
+    }
+}
+
+template <int RB, int NP>
+__device__ __forceinline__ void gather_finish(GReg<RB> &g, uint16_t *__restrict__ Abuf, const lgcn_agg_mlp_t &p, int ri,
+                                              int gt, const TileIdx<RB> &ix) {
+    constexpr int IT = GReg<RB>::IT;
+    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(p.rel[ri].src);
+    const int mode = p.rel[ri].mode;
+    const int hw = gt >> 5, l = gt & 31;
+    const bool lds_col = ix.flag[0] != 0;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        float4 s = g.b[it] < g.e[it] ? g.s[it] : make_float4(0.f, 0.f, 0.f, 0.f);
+        int j = g.b[it] + 1;
+        for (; j + 3 < g.e[it]; j += 4) {  // four loads in flight, summed in index order
+            float4 x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) x[q] = src[(int64_t)gather_source<RB>(p, ix, mode, lds_col, g.cadj[it], j + q) * 32 + l];
+            s = f4add(f4add(f4add(f4add(s, x[0]), x[1]), x[2]), x[3]);
+        }
+        for (; j < g.e[it]; ++j) s = f4add(s, src[(int64_t)gather_source<RB>(p, ix, mode, lds_col, g.cadj[it], j) * 32 + l]);
+        split_store<NP>(Abuf, Tile<RB, NP>::PLANE, it * 8 + hw, 4 * l, s);
+    }
+}
+
+template <int RB, int NP, int KIND>
+__global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
+    using TL = Tile<RB, NP>;
+    using IX = TileIdx<RB>;
+    constexpr int ROWS = TL::ROWS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TL::SMEM + 128 + IX::INTS * 4];
+    uint16_t *buf0 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *buf1 = reinterpret_cast<uint16_t *>(smem + TL::ABUF_BYTES);
+    float *T = reinterpret_cast<float *>(smem);                                 // aliases the A buffers
+    uint16_t *Yp = reinterpret_cast<uint16_t *>(smem + TL::T_BYTES);            // stage-2 operand planes
+    int *act = reinterpret_cast<int *>(smem + TL::SMEM);                        // [0..15] ids, [16] count
+    const IX ix(reinterpret_cast<int *>(smem + TL::SMEM + 128));
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_chunk_remap(blockIdx.x, n_tiles);
+    const int64_t row0 = (int64_t)tile * ROWS;
+    const int64_t n_sub = (p.n_rows + 15) >> 4;
+    const int nrc = p.n_rel_csr;
+    const bool has_csr = KIND == 1, has_rng = KIND == 0 && p.rowptr != nullptr;
+
+    // ---- index slice -> LDS
+    if (has_csr) {
+        const int len = nrc * 16 + 1;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int64_t sub = (int64_t)tile * RB + rb;
+            for (int j = tid; j < len; j += 512) ix.rp[rb * IX::RP + j] = sub < n_sub ? p.rowptr[sub * nrc * 16 + j] : 0;
+        }
+    } else if (has_rng) {
+        for (int j = tid; j <= ROWS; j += 512) {
+            const int64_t n = row0 + j < p.n_rows ? row0 + j : p.n_rows;
+            ix.rng[j] = p.rowptr[n];
+        }
+    }
+    __syncthreads();
+    if (has_csr) {
+        int lo = 0;
+        bool fits = true;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {     // every thread computes the same (uniform) layout
+            const int c0 = ix.rp[rb * IX::RP], c1 = ix.rp[rb * IX::RP + nrc * 16];
+            if (tid == 0) { ix.c0[rb] = c0; ix.lo[rb] = lo; }
+            lo += c1 - c0;
+        }
+        fits = lo <= IX::COLCAP;
+        if (tid == 0) ix.flag[0] = fits ? 1 : 0;
+        if (fits) {
+            lo = 0;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int c0 = ix.rp[rb * IX::RP], c1 = ix.rp[rb * IX::RP + nrc * 16];
+                for (int j = tid; j < c1 - c0; j += 512) ix.col[lo + j] = p.col[c0 + j];
+                lo += c1 - c0;
+            }
+        }
+    } else if (tid == 0) {
+        ix.flag[0] = 0;
+    }
+    // ---- active relations of this tile (wave 7 so that it overlaps the col copy of the others)
+    if (wave == 7) {
+        bool on = false;
+        if (lane < p.n_rel) {
+            const int mode = p.rel[lane].mode;
+            if (mode == LGCN_REL_CSR) {
+                const int r = p.rel[lane].ridx;
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    on = on || ix.rp[rb * IX::RP + r * 16 + 16] > ix.rp[rb * IX::RP + r * 16];
+            } else if (mode == LGCN_REL_RANGE) {
+                on = ix.rng[ROWS] > ix.rng[0];
+            } else {
+                on = true;
+            }
+        }
+        const unsigned long long m = __ballot(on);
+        if (on) act[__popcll(m & ((1ull << lane) - 1ull))] = lane;
+        if (lane == 0) act[16] = __popcll(m);
+    }
+    __syncthreads();
+    const int nact = __builtin_amdgcn_readfirstlane(act[16]);
+
+    // ---- main loop: MFMA waves run pass i on buffer i & 1 while the gather waves fill the other buffer
+    // with relation i + 1 (one barrier per relation).  Latency is hidden across workgroups (keep the
+    // VGPR count <= 128 so that two 8-wave workgroups fit a CU): a deeper per-wave register ring was
+    // measured slower because it halves that occupancy.
+    const int flags = p.flags;
+    const bool two = (flags & LGCN_F_GEMM2) != 0;
+    const int gt = tid - 256;
+    auto rel_at = [&](int i) { return __builtin_amdgcn_readfirstlane(act[i]); };
+    BRing<NP> bfrag;
+    if (wave >= 4) {
+        if (nact > 0) {
+            GReg<RB> g;
+            gather_issue<RB>(g, p, rel_at(0), tile, gt, ix);
+            gather_finish<RB, NP>(g, buf0, p, rel_at(0), gt, ix);
+        }
+    } else {
+        const float *w0 = nact > 0 ? p.rel[rel_at(0)].wp : p.wp2;
+        if (w0 != nullptr) ring_prime<NP>(bfrag, reinterpret_cast<const uint4 *>(w0), wave, lane);
+    }
+    __syncthreads();
+
+    f32x4 acc[RB][2];
+    acc_zero<RB>(acc);
+    for (int i = 0; i < nact; ++i) {
+        uint16_t *cur = (i & 1) ? buf1 : buf0;
+        uint16_t *nxt = (i & 1) ? buf0 : buf1;
+        if (wave < 4) {
+            if (!(flags & (1 << 9))) {   // timing-only ablation bit (tools/bench_agg.py): skip the MFMA passes
+            const float *wn = i + 1 < nact ? p.rel[rel_at(i + 1)].wp : (two ? p.wp2 : nullptr);
+            gemm_pass<RB, NP>(cur, reinterpret_cast<const uint4 *>(p.rel[rel_at(i)].wp),
+                              reinterpret_cast<const uint4 *>(wn), bfrag, wave, lane, acc);
+            }
+        } else if (i + 1 < nact && !(flags & (1 << 8))) {   // ablation bit: skip the in-loop gathers
+            GReg<RB> g;
+            gather_issue<RB>(g, p, rel_at(i + 1), tile, gt, ix);
+            gather_finish<RB, NP>(g, nxt, p, rel_at(i + 1), gt, ix);
+        }
+        __syncthreads();
+    }
+
+    if (wave < 4) {
+        if (p.w4 != nullptr) {  // rank-4 fp32 update: the 4 meta channels of A2M.meta
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                const float4 wc = *reinterpret_cast<const float4 *>(p.w4 + 4 * (32 * wave + 16 * cb + (lane & 15)));
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int64_t n = row0 + 16 * rb + 4 * (lane >> 4) + i;
+                        if (n < p.n_rows) {
+                            const float2 tu = reinterpret_cast<const float2 *>(p.x4_a)[n];
+                            acc[rb][cb][i] += tu.x * wc.x + tu.y * wc.y + p.x4_b[n] * wc.z + p.x4_c[n] * wc.w;
+                        }
+                    }
+            }
+        }
+        acc_store<RB>(T, acc, lane, wave);
+    }
+    __syncthreads();
+
+    if (tid < 256) {
+#pragma unroll
+        for (int c0 = 0; c0 < ROWS; c0 += 32) {
+            const int row = c0 + (tid >> 3);
+            if (row < ROWS) {
+                const int64_t n = row0 + row;
+                const bool live = n < p.n_rows;
+                RowVals r = row_load(T + c0 * kLDA, tid);
+                if (live && p.out_pre) row_store_global(p.out_pre + n * kC, tid, r);
+                if (flags & LGCN_F_GN1) row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
+                if (!two && live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
+                if (flags & LGCN_F_RELU1) row_relu(r);
+                if (two) row_split_store<NP>(Yp, TL::PLANE, row, tid, r);
+                else if (live) row_store_global(p.out + n * kC, tid, r);
+            }
+        }
+    }
+    if (!two) return;
+    __syncthreads();
+    if (wave < 4) {
+        acc_zero<RB>(acc);
+        gemm_pass<RB, NP>(Yp, reinterpret_cast<const uint4 *>(p.wp2), nullptr, bfrag, wave, lane, acc);
+        acc_store<RB>(T, acc, lane, wave);   // T and Yp are disjoint; T's readers passed the barrier above
+    }
+    __syncthreads();
+    if (tid < 256) {
+#pragma unroll
+        for (int c0 = 0; c0 < ROWS; c0 += 32) {
+            const int row = c0 + (tid >> 3);
+            if (row < ROWS) {
+                const int64_t n = row0 + row;
+                const bool live = n < p.n_rows;
+                RowVals r = row_load(T + c0 * kLDA, tid);
+                if (flags & LGCN_F_GN2) row_gn(r, tid, p.gn2_g, p.gn2_b, p.eps);
+                if (live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
+                if (flags & LGCN_F_RELU2) row_relu(r);
+                if (live) row_store_global(p.out + n * kC, tid, r);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------- shared pieces -----
+// h1[row][c] = ReLU(w1[c][0] x + w1[c][1] y + b1[c]) for the thread's 16 channels, split into planes
+template <int NP>
+__device__ __forceinline__ void lin2_relu_split(uint16_t *planes, int plane_elems, int row, int t, float x, float y,
+                                                const float *__restrict__ w1, const float *__restrict__ b1) {
+    const int c0 = 4 * (t & 7);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + 32 * j;
+        const float4 wa = *reinterpret_cast<const float4 *>(w1 + 2 * c);
+        const float4 wb = *reinterpret_cast<const float4 *>(w1 + 2 * c + 4);
+        const float4 bb = *reinterpret_cast<const float4 *>(b1 + c);
+        float4 o;
+        o.x = fmaxf(x * wa.x + y * wa.y + bb.x, 0.f);
+        o.y = fmaxf(x * wa.z + y * wa.w + bb.y, 0.f);
+        o.z = fmaxf(x * wb.x + y * wb.y + bb.z, 0.f);
+        o.w = fmaxf(x * wb.z + y * wb.w + bb.w, 0.f);
+        split_store<NP>(planes, plane_elems, row, c, o);
+    }
+}
+
+template <int RB, int NP>
+__global__ __launch_bounds__(256) void k_mapnet_input_bf(const InputParams p, int n_tiles) {
+    using TL = Tile<RB, NP>;
+    constexpr int ROWS = TL::ROWS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TL::ABUF_BYTES + TL::T_BYTES];
+    uint16_t *A = reinterpret_cast<uint16_t *>(smem);
+    float *T = reinterpret_cast<float *>(smem + TL::ABUF_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * ROWS;
+    f32x4 acc[RB][2];
+    RowVals keep[(ROWS + 31) / 32];
+
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {
+        const float2 *xy = reinterpret_cast<const float2 *>(br == 0 ? p.ctrs : p.feats);
+        const float *w1 = br == 0 ? p.wa1 : p.ws1, *b1 = br == 0 ? p.ba1 : p.bs1;
+        const float *wp = br == 0 ? p.wpa2 : p.wps2;
+        const float *g = br == 0 ? p.ga : p.gs, *bt = br == 0 ? p.bta : p.bts;
+#pragma unroll
+        for (int c0 = 0; c0 < ROWS; c0 += 32) {
+            const int row = c0 + (tid >> 3);
+            if (row < ROWS) {
+                float2 v = make_float2(0.f, 0.f);
+                if (row0 + row < p.n_rows) v = xy[row0 + row];
+                lin2_relu_split<NP>(A, TL::PLANE, row, tid, v.x, v.y, w1, b1);
+            }
+        }
+        __syncthreads();
+        acc_zero<RB>(acc);
+        {
+            BRing<NP> bf;
+            ring_prime<NP>(bf, reinterpret_cast<const uint4 *>(wp), wave, lane);
+            gemm_pass<RB, NP>(A, reinterpret_cast<const uint4 *>(wp), nullptr, bf, wave, lane, acc);
+        }
+        acc_store<RB>(T, acc, lane, wave);
+        __syncthreads();
+#pragma unroll
+        for (int c0 = 0; c0 < ROWS; c0 += 32) {
+            const int row = c0 + (tid >> 3);
+            if (row < ROWS) {
+                RowVals r = row_load(T + c0 * kLDA, tid);
+                row_gn(r, tid, g, bt, p.eps);
+                if (br == 0) {
+                    keep[c0 / 32] = r;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) r.v[j] = f4add(r.v[j], keep[c0 / 32].v[j]);
+                    row_relu(r);
+                    if (row0 + row < p.n_rows) row_store_global(p.out + (row0 + row) * kC, tid, r);
+                }
+            }
+        }
+        // branch 1 rewrites A (its readers passed the barrier above) and T (read by the same threads)
+    }
+}
+
+template <int RB, int NP>
+__global__ __launch_bounds__(256) void k_att_pairs_bf(const PairParams p) {
+    using TL = Tile<RB, NP>;
+    constexpr int ROWS = TL::ROWS;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TL::ABUF_BYTES + TL::T_BYTES];
+    uint16_t *A = reinterpret_cast<uint16_t *>(smem);
+    float *T = reinterpret_cast<float *>(smem + TL::ABUF_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t P = *p.n_pairs;
+    if (P < 0 || P > p.cap) P = p.cap;
+    const int64_t n_tiles = (P + ROWS - 1) / ROWS;
+    f32x4 acc[RB][2];
+    const uint4 *wd2 = reinterpret_cast<const uint4 *>(p.wpd2), *wc0 = reinterpret_cast<const uint4 *>(p.wpc0e);
+    BRing<NP> bf;
+    if ((int64_t)blockIdx.x < n_tiles) ring_prime<NP>(bf, wd2, wave, lane);
+
+    for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int64_t pr0 = tile * ROWS;
+#pragma unroll
+        for (int c0 = 0; c0 < ROWS; c0 += 32) {
+            const int row = c0 + (tid >> 3);
+            if (row < ROWS) {
+                float dx = 0.f, dy = 0.f;
+                if (pr0 + row < P) {
+                    const float2 a = reinterpret_cast<const float2 *>(p.agt_ctrs)[p.hi[pr0 + row]];
+                    const float2 c = reinterpret_cast<const float2 *>(p.ctx_ctrs)[p.wi[pr0 + row]];
+                    dx = a.x - c.x; dy = a.y - c.y;
+                }
+                lin2_relu_split<NP>(A, TL::PLANE, row, tid, dx, dy, p.wd0, p.bd0);
+            }
+        }
+        __syncthreads();
+        acc_zero<RB>(acc);
+        gemm_pass<RB, NP>(A, wd2, wc0, bf, wave, lane, acc);
+        acc_store<RB>(T, acc, lane, wave);
+        __syncthreads();   // all waves done reading A; T complete
+#pragma unroll
+        for (int c0 = 0; c0 < ROWS; c0 += 32) {
+            const int row = c0 + (tid >> 3);
+            if (row < ROWS) {
+                RowVals r = row_load(T + c0 * kLDA, tid);
+                row_gn(r, tid, p.gd, p.btd, p.eps);
+                row_relu(r);
+                row_split_store<NP>(A, TL::PLANE, row, tid, r);
+            }
+        }
+        __syncthreads();
+        acc_zero<RB>(acc);
+        gemm_pass<RB, NP>(A, wc0, wd2, bf, wave, lane, acc);   // prefetches the next tile's first fragments
+        acc_store<RB>(T, acc, lane, wave);   // T's readers (previous row phase) passed the barrier above
+        __syncthreads();
+#pragma unroll
+        for (int c0 = 0; c0 < ROWS; c0 += 32) {
+            const int row = c0 + (tid >> 3);
+            if (row < ROWS) {
+                const int64_t pr = pr0 + row;
+                const bool live = pr < P;
+                RowVals r = row_load(T + c0 * kLDA, tid);
+                if (live) {
+                    row_add_global(r, p.U + (int64_t)p.hi[pr] * kC, tid);
+                    row_add_global(r, p.V + (int64_t)p.wi[pr] * kC, tid);
+                }
+                row_gn(r, tid, p.gc, p.btc, p.eps);
+                row_relu(r);
+                if (live) row_store_global(p.m + pr * kC, tid, r);
+            }
+        }
+        __syncthreads();   // next tile rewrites A (read by the last gemm) and T (read just above)
+    }
+}
+
+// ------------------------------------------------------------ dispatch -----
+static int cu_count() {
+    static int n = 0;   // read-only cache of a device attribute
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
+// 16-row blocks per tile: fewest rounds over the CUs, then the tallest tile (weight reuse)
+static int pick_rb(int64_t n_rows, int wgs_per_cu) {
+    const int64_t n_sub = (n_rows + 15) / 16;
+    const int64_t slots = (int64_t)cu_count() * wgs_per_cu;
+    int best = 1;
+    int64_t best_cost = -1;
+    for (int rb = 1; rb <= 4; ++rb) {
+        const int64_t tiles = (n_sub + rb - 1) / rb;
+        const int64_t cost = ((tiles + slots - 1) / slots) * rb;
+        if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = rb; }
+    }
+    return best;
+}
+
+template <int NP>
+static void launch_agg(const lgcn_agg_mlp_t &p, int rb, bool lane_conv, hipStream_t st) {
+    const int rows = 16 * rb;
+    const int n_tiles = (int)((p.n_rows + rows - 1) / rows);
+#define LGCN_AGG(RB_)                                                                                          \
+    if (lane_conv) hipLaunchKernelGGL((k_agg_mlp_bf<RB_, NP, 1>), dim3(n_tiles), dim3(512), 0, st, p, n_tiles); \
+    else hipLaunchKernelGGL((k_agg_mlp_bf<RB_, NP, 0>), dim3(n_tiles), dim3(512), 0, st, p, n_tiles)
+    switch (rb) {
+        case 1: LGCN_AGG(1); break;
+        case 2: LGCN_AGG(2); break;
+        case 3: LGCN_AGG(3); break;
+        default: LGCN_AGG(4); break;
+    }
+#undef LGCN_AGG
+}
+
+int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st) {
+    int rb = p.tile_rb;
+    if (rb < 0 || rb > 4) return LGCN_EINVAL;
+    if (rb == 0) rb = pick_rb(p.n_rows, 1);
+    if (p.mma == LGCN_MMA_BF16X3) launch_agg<3>(p, rb, lane_conv, st);
+    else launch_agg<1>(p, rb, lane_conv, st);
+    return launch_status();
+}
+
+int mapnet_input_bf(const InputParams &p, int mma, hipStream_t st) {
+    const int rb = pick_rb(p.n_rows, 2);
+    const int n_tiles = (int)((p.n_rows + 16 * rb - 1) / (16 * rb));
+#define LGCN_IN(RB_, NP_) hipLaunchKernelGGL((k_mapnet_input_bf<RB_, NP_>), dim3(n_tiles), dim3(256), 0, st, p, n_tiles)
+    if (mma == LGCN_MMA_BF16X3) {
+        switch (rb) { case 1: LGCN_IN(1, 3); break; case 2: LGCN_IN(2, 3); break; case 3: LGCN_IN(3, 3); break; default: LGCN_IN(4, 3); }
+    } else {
+        switch (rb) { case 1: LGCN_IN(1, 1); break; case 2: LGCN_IN(2, 1); break; case 3: LGCN_IN(3, 1); break; default: LGCN_IN(4, 1); }
+    }
+#undef LGCN_IN
+    return launch_status();
+}
+
+int att_pairs_bf(const PairParams &p, int mma, hipStream_t st) {
+    // 32-pair tiles (RB = 2): ~43 KB of LDS, so 3 workgroups share a CU and cover each other's
+    // row phases (this kernel has no separate gather waves)
+    const int64_t tiles = (p.cap + 31) / 32;
+    const int64_t slots = (int64_t)cu_count() * 3;
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    if (mma == LGCN_MMA_BF16X3) hipLaunchKernelGGL((k_att_pairs_bf<2, 3>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((k_att_pairs_bf<2, 1>), dim3(grid), dim3(256), 0, st, p);
+    return launch_status();
+}
+
+int pack_weight_bf(const float *W, int ld, int n_planes, void *out, hipStream_t st) {
+    hipLaunchKernelGGL(k_pack_weight_bf, dim3(8), dim3(256), 0, st, W, ld, n_planes, reinterpret_cast<uint16_t *>(out));
+    return launch_status();
+}
+
+}  // namespace lgcn

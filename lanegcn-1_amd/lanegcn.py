@@ -180,7 +180,7 @@ def _fuse_modules(n_map: int, num_scales: int, ng: int = 1) -> nn.ModuleDict:
     return nn.ModuleDict(fuse)
 
 
-def lane_conv(fuse: nn.ModuleDict, feat: Tensor, plan: ops.LanePlan, num_scales: int) -> Tensor:
+def lane_conv(fuse: nn.ModuleDict, feat: Tensor, plan: ops.LanePlan, num_scales: int, tile_rb: int = 0) -> Tensor:
     """4 LaneConv layers, one fused launch each (reference lanegcn.py:331-362 == 448-479)."""
     keys = rel_keys(num_scales)
     for i in range(len(fuse["ctr"])):
@@ -191,7 +191,7 @@ def lane_conv(fuse: nn.ModuleDict, feat: Tensor, plan: ops.LanePlan, num_scales:
         c2 = fuse["ctr2"][i]
         feat = ops.agg_mlp(feat.shape[0], rels, _FULL, rowptr=plan.rowptr, col=plan.col, n_rel_csr=plan.n_rel,
                            gn1=_gn(fuse["norm"][i]), wp2=ops.packed(c2.linear.weight), gn2=_gn(c2.norm),
-                           res=feat, eps=fuse["norm"][i].eps, tag="laneconv")
+                           res=feat, eps=fuse["norm"][i].eps, tag="laneconv", tile_rb=tile_rb)
     return feat
 
 

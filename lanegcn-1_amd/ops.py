@@ -11,9 +11,26 @@ import torch
 
 from . import _lib as L
 
+import os
+
 C_FEAT = 128
-TM = 32
 EPS = 1e-5
+
+# How the 128-d contractions run on the matrix cores (include/lgcn.h, LGCN_MMA_*):
+#   "f32"    exact fp32 fma chain (v_mfma_f32_32x32x2_f32)
+#   "bf16x3" 3-way bf16 split, 6 products, fp32 accumulate: fp32-grade, 2.67x the f32 MFMA rate
+#   "bf16"   single bf16 product (BASELINE config "bf16"; not within 1e-4)
+_mma = L.MMA_NAMES[os.environ.get("LGCN_MMA", "bf16x3")]
+
+
+def set_mma(name: str):
+    """Select the matrix-core mode for subsequent launches ("f32" | "bf16x3" | "bf16")."""
+    global _mma
+    _mma = L.MMA_NAMES[name]
+
+
+def get_mma() -> str:
+    return {v: k for k, v in L.MMA_NAMES.items()}[_mma]
 
 
 def _stream():
@@ -172,16 +189,21 @@ def packed(weight: torch.Tensor, col0: int = 0, k: Optional[int] = None) -> torc
         raise L.LgcnError("packed(): weight must be [128, K]")
     k = weight.shape[1] - col0 if k is None else k
 
+    mma = _mma
+
     def make():
         w = _dev(weight.detach(), torch.float32, "weight")
         k_pad = (k + 7) // 8 * 8
-        out = torch.empty(C_FEAT * k_pad, dtype=torch.float32, device=w.device)
+        nbytes = lib.lgcn_packed_bytes(k_pad, mma)
+        if nbytes < 0:
+            raise L.LgcnError("packed(): K = %d is not supported in mma mode %d" % (k, mma))
+        out = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
         src = w[:, col0:]
-        L.check(lib.lgcn_pack_weight(C.c_void_p(src.data_ptr()), w.stride(0), k, k_pad, _ptr(out), _stream()),
+        L.check(lib.lgcn_pack_weight(C.c_void_p(src.data_ptr()), w.stride(0), k, k_pad, mma, _ptr(out), _stream()),
                 "lgcn_pack_weight")
         return out
 
-    return _cached(weight, ("pack", col0, k), make)
+    return _cached(weight, ("pack", col0, k, mma), make)
 
 
 def cols4(weight: torch.Tensor, col0: int) -> torch.Tensor:
@@ -243,7 +265,7 @@ class RelSpec:
 
 
 def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, col=None, n_rel_csr=0,
-            gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, eps=EPS, tag=None):
+            gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, eps=EPS, tag=None, tile_rb=0):
     """Fused aggregate -> GEMM -> GN -> ReLU -> GEMM -> GN -> +res -> ReLU row block (lgcn_agg_mlp)."""
     lib = L.load()
     if not rels or len(rels) > L.MAX_REL:
@@ -251,6 +273,7 @@ def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, co
     dev = rels[0].src.device
     p = L.AggMlp()
     p.n_rows, p.n_rel, p.n_rel_csr, p.flags, p.eps = n_rows, len(rels), n_rel_csr, flags, eps
+    p.mma, p.tile_rb = _mma, tile_rb
     keep = []
     for i, r in enumerate(rels):
         s = _dev(r.src, torch.float32, "rel.src")
@@ -289,7 +312,7 @@ def mapnet_input(ctrs, feats, wa1, ba1, wpa2, gn_a, ws1, bs1, wps2, gn_s, eps=EP
     out = torch.empty((n, C_FEAT), dtype=torch.float32, device=ctrs.device)
     L.check(lib.lgcn_mapnet_input(_ptr(ctrs), _ptr(feats), n, _ptr(wa1), _ptr(ba1), _ptr(wpa2), _ptr(gn_a[0]),
                                   _ptr(gn_a[1]), _ptr(ws1), _ptr(bs1), _ptr(wps2), _ptr(gn_s[0]), _ptr(gn_s[1]),
-                                  eps, _ptr(out), _stream()), "lgcn_mapnet_input")
+                                  eps, _mma, _ptr(out), _stream()), "lgcn_mapnet_input")
     return out
 
 
@@ -300,6 +323,6 @@ def att_pairs(ps: PairSet, wd0, bd0, wpd2, gn_d, wpc0e, U, V, gn_c, m=None, eps=
     with _Timed(tag):
         rc = lib.lgcn_att_pairs(_ptr(ps.agt_ctrs), _ptr(ps.ctx_ctrs), _ptr(ps.hi), _ptr(ps.wi), _ptr(ps.n_pairs),
                                 ps.cap, _ptr(wd0), _ptr(bd0), _ptr(wpd2), _ptr(gn_d[0]), _ptr(gn_d[1]), _ptr(wpc0e),
-                                _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _ptr(m), _stream())
+                                _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _mma, _ptr(m), _stream())
     L.check(rc, "lgcn_att_pairs")
     return m

@@ -22,6 +22,17 @@ def hip():
     return M, ops
 
 
+@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+def mma_mode(request, hip):
+    """Every test runs on both matrix-core modes that claim fp32 parity: the exact f32 MFMA chain and
+    the 3-way-split bf16 MFMA (6 products).  Same 1e-4 bar for both."""
+    _, ops = hip
+    prev = ops.get_mma()
+    ops.set_mma(request.param)
+    yield request.param
+    ops.set_mma(prev)
+
+
 def make_modules(M, sd, device="cuda"):
     mods = {}
     for name, cls in (("map_net", M.MapNet), ("a2m", M.A2M), ("m2m", M.M2M), ("m2a", M.M2A), ("a2a", M.A2A)):
@@ -106,13 +117,13 @@ def expand_plan(plan):
     rp = plan.rowptr.cpu().numpy().astype(np.int64)
     col = plan.col.cpu().numpy()
     out = []
-    n_tiles = (plan.n_nodes + 31) // 32
-    for t in range(n_tiles):
+    n_sub = (plan.n_nodes + 15) // 16
+    for t in range(n_sub):
         for r in range(plan.n_rel):
-            for j in range(32):
-                k = (t * plan.n_rel + r) * 32 + j
+            for j in range(16):
+                k = (t * plan.n_rel + r) * 16 + j
                 for e in range(rp[k], rp[k + 1]):
-                    out.append((r, t * 32 + j, int(col[e])))
+                    out.append((r, t * 16 + j, int(col[e])))
     return sorted(out)
 
 
@@ -328,3 +339,40 @@ def test_full_net_forward_vs_reference(golden, ref_state_names, hip):
         assert float(np.abs(cls - golden["net/cls/%d" % i]).max()) <= 2e-4, i
         # reg carries world coordinates up to ~1e3 m (scene 1 is offset by 1000 m): fp32 ulp there is 6e-5
         assert np.allclose(reg, golden["net/reg/%d" % i], rtol=1e-6, atol=5e-4), i
+
+
+def test_bf16_single_product_mode(gcase, golden, hip):
+    """BASELINE config "bf16" (one bf16 product, fp32 accumulate / GN): no fp32 parity claim; over the whole
+    16-layer path the features stay within 2e-2 relative (Frobenius) / 0.2 absolute of the reference
+    (SURVEY.md hard part 6 suggests 2e-2 relative)."""
+    M, ops = hip
+    scenes, _, mods = gcase
+    prev = ops.get_mma()
+    ops.set_mma("bf16")
+    try:
+        out, _ = run_hot_path(M, mods, scenes, torch.from_numpy(golden["actors_in"]))
+    finally:
+        ops.set_mma(prev)
+    for k in ("map_net", "a2m", "m2m", "m2a", "a2a"):
+        err = float(np.abs(out[k] - golden[k]).max())
+        rel = float(np.linalg.norm(out[k] - golden[k]) / np.linalg.norm(golden[k]))
+        assert np.isfinite(out[k]).all() and 1e-5 < err <= 0.2 and rel <= 2e-2, (k, err, rel)
+
+
+def test_tile_heights_agree(hip, ref_state_names):
+    """Every tile height (16/32/48/64 rows) of the split-bf16 LaneConv kernel gives the same layer output
+    (same per-row arithmetic; only the work decomposition changes)."""
+    M, ops = hip
+    if ops.get_mma() == "f32":
+        pytest.skip("tile height is a split-bf16 kernel parameter")
+    from lanegcn_amd import data as gen
+    sd = O.seeded_state(ref_state_names, 5)
+    mods = make_modules(M, sd)
+    scenes = [to_torch_scene(s) for s in gen.synth_batch("S2", seed=3, n_scenes=3)]
+    with torch.no_grad():
+        graph = M.graph_gather([s["graph"] for s in scenes])
+        feat = mods["map_net"].stem(torch.cat(graph["ctrs"], 0), graph["feats"])
+        plan = M.lane_plan(graph)
+        outs = [M.lane_conv(mods["map_net"].fuse, feat, plan, 6, tile_rb=rb).cpu().numpy() for rb in (1, 2, 3, 4)]
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)

@@ -42,14 +42,17 @@ def test_struct_layout_matches_header(lib):
     _, mod = lib
     # lgcn_rel_t: 2 pointers + 2 int32; lgcn_agg_mlp_t: 24-byte head, 16 rels, 14 pointers
     assert C.sizeof(mod.Rel) == 24
-    assert mod.AggMlp.rel.offset == 24
-    assert C.sizeof(mod.AggMlp) == 24 + 16 * 24 + 14 * 8
+    assert mod.AggMlp.rel.offset == 32
+    assert C.sizeof(mod.AggMlp) == 32 + 16 * 24 + 14 * 8
 
 
 def test_size_helpers(lib):
     l, _ = lib
-    assert l.lgcn_csr_rowptr_elems(10368, 14) == 324 * 14 * 32 + 1
-    assert l.lgcn_csr_rowptr_elems(33, 14) == 2 * 14 * 32 + 1
+    assert l.lgcn_csr_rowptr_elems(10368, 14) == 648 * 14 * 16 + 1
+    assert l.lgcn_csr_rowptr_elems(33, 14) == 3 * 14 * 16 + 1
+    assert l.lgcn_packed_bytes(128, 0) == 65536 and l.lgcn_packed_bytes(136, 0) == 128 * 136 * 4
+    assert l.lgcn_packed_bytes(128, 1) == 3 * 32768 and l.lgcn_packed_bytes(128, 2) == 32768
+    assert l.lgcn_packed_bytes(136, 1) < 0 and l.lgcn_packed_bytes(128, 9) < 0
     assert l.lgcn_csr_rowptr_elems(10, 17) < 0
     assert l.lgcn_csr_ws_elems(10368, 14) > l.lgcn_csr_rowptr_elems(10368, 14)
     assert l.lgcn_pairs_ws_elems(1600, 32) >= 1601 + 64
@@ -61,9 +64,11 @@ def test_bad_arguments_are_refused_without_launching(lib):
     assert l.lgcn_graph_gather(None, 5, None, None, 1, None, None, None) == EINVAL
     assert l.lgcn_graph_gather(None, 0, None, None, 0, None, None, None) == 0          # empty: nothing to do
     assert l.lgcn_graph_gather(None, -1, None, None, 0, None, None, None) == EINVAL
-    assert l.lgcn_pack_weight(None, 128, 128, 128, None, None) == EINVAL
-    assert l.lgcn_pack_weight(C.c_void_p(64), 128, 128, 130, C.c_void_p(64), None) == EINVAL   # k_pad % 8
-    assert l.lgcn_pack_weight(C.c_void_p(64), 128, 128, 128, C.c_void_p(68), None) == EALIGN
+    assert l.lgcn_pack_weight(None, 128, 128, 128, 0, None, None) == EINVAL
+    assert l.lgcn_pack_weight(C.c_void_p(64), 128, 128, 130, 0, C.c_void_p(64), None) == EINVAL   # k_pad % 8
+    assert l.lgcn_pack_weight(C.c_void_p(64), 128, 128, 128, 0, C.c_void_p(68), None) == EALIGN
+    assert l.lgcn_pack_weight(C.c_void_p(64), 128, 128, 128, 5, C.c_void_p(64), None) == EINVAL   # unknown mma
+    assert l.lgcn_pack_weight(C.c_void_p(64), 136, 132, 136, 1, C.c_void_p(64), None) == -2       # bf16 modes: K = 128 only
     p = mod.AggMlp()
     assert l.lgcn_agg_mlp(None, None) == EINVAL
     p.n_rows, p.n_rel = 10, 0
@@ -85,9 +90,10 @@ def test_bad_arguments_are_refused_without_launching(lib):
     p.rel[0].src = 260
     assert l.lgcn_agg_mlp(C.byref(p), None) == EALIGN
     assert l.lgcn_pairs_build(None, None, None, None, 0, 0, 0, 1.0, 1, None, None, 0, None, None, None, None) == EINVAL
-    assert l.lgcn_att_pairs(*([None] * 5), -1, *([None] * 10), 1e-5, None, None) == EINVAL
-    assert l.lgcn_att_pairs(*([None] * 5), 0, *([None] * 10), 1e-5, None, None) == 0
-    assert l.lgcn_mapnet_input(None, None, 5, *([None] * 10), 1e-5, None, None) == EINVAL
+    assert l.lgcn_att_pairs(*([None] * 5), -1, *([None] * 10), 1e-5, 0, None, None) == EINVAL
+    assert l.lgcn_att_pairs(*([None] * 5), 0, *([None] * 10), 1e-5, 0, None, None) == 0
+    assert l.lgcn_att_pairs(*([None] * 5), 0, *([None] * 10), 1e-5, 3, None, None) == EINVAL
+    assert l.lgcn_mapnet_input(None, None, 5, *([None] * 10), 1e-5, 1, None, None) == EINVAL
 
 
 def test_product_never_imports_the_oracle():
