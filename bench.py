@@ -26,9 +26,10 @@ sys.path.insert(0, ROOT)
 C = 128
 # Dense matrix-core peaks (MI355X_MICROARCH.md).  The split mode spends 6 bf16 products per fp32-grade
 # multiply-add, so its effective peak in fp32-equivalent flops is the bf16 peak / 6.
-PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 6.0, "bf16": 2500.0}
+PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 6.0, "f16x2": 2500.0 / 3.0, "bf16": 2500.0}
 PEAK_NOTE = {"f32": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), 157.3 TF dense",
              "bf16x3": "bf16 MFMA dense 2.5 PF / 6 products of the 3-way split (fp32-grade result)",
+             "f16x2": "fp16 MFMA dense 2.5 PF / 3 products of the 2-way split (fp32-grade result)",
              "bf16": "bf16 MFMA dense 2.5 PF"}
 PEAK_HBM_GBPS = 8000.0             # HBM3E spec
 
@@ -131,10 +132,10 @@ def main():
     ap.add_argument("--scenes", type=int, default=None, help="override scenes per batch (S2: 32)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--streams", type=int, default=1,
+    ap.add_argument("--streams", type=int, default=4,
                     help="forward graphs kept in flight on separate HIP streams (each on its own batch)")
-    ap.add_argument("--mma", default=None, choices=["f32", "bf16x3", "bf16"],
-                    help="matrix-core mode (default: LGCN_MMA or bf16x3 = fp32-grade 3-way bf16 split)")
+    ap.add_argument("--mma", default=None, choices=["f32", "bf16x3", "f16x2", "bf16"],
+                    help="matrix-core mode (default: LGCN_MMA or f16x2 = fp32-grade 2-way fp16 split)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,6 +210,17 @@ def main():
     elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)     # slowest rank
 
     log("rank %d: %d steps in %.4f s" % (rank, args.steps, elapsed))
+    single = None
+    if not args.no_graph and args.streams > 1:       # same steps, one forward at a time (latency view)
+        g1 = lanes[0][1]
+        for _ in range(args.warmup):
+            g1.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            g1.replay()
+        torch.cuda.synchronize()
+        single = D.max_over_ranks(time.perf_counter() - t1, dev)
     # per-kernel durations (HIP events on the launch stream), eager launches of the same forward
     with ops.kernel_timer() as kt:
         for _ in range(10):
@@ -252,7 +264,11 @@ def main():
                 "hbm_frac_algorithmic": byts / (lc_ms * 1e-3) / 1e9 / PEAK_HBM_GBPS,
             },
             "kernel_avg_us": {k: float(np.mean(v)) * 1e3 for k, v in ksum.items()},
+            "streams": 1 if args.no_graph else args.streams,
         }
+        if single is not None:
+            line["single_stream"] = {"value": args.gpus * n_scenes * args.steps / single, "unit": "scenes/s",
+                                     "ms_per_step": single / args.steps * 1e3}
         if args.cpu_seconds > 0:
             line["cpu_baseline"] = cpu_baseline(scenes, actors_cpu, mods, args.cpu_seconds)
             line["speedup_vs_cpu_all_cores"] = line["value"] / args.gpus / line["cpu_baseline"]["value"]

@@ -125,8 +125,14 @@ int lgcn_widen_i32(const int32_t *in, const int32_t *n_dev, int64_t cap,
  *                   v_mfma_f32_16x16x32_bf16 with fp32 accumulation: fp32-grade result
  *                   (dropped terms <= 2^-24 relative) at 2.67x the f32 MFMA rate.
  *   LGCN_MMA_BF16   one bf16 product (BASELINE config "bf16"; ~2e-2 relative on features).
+ *   LGCN_MMA_F16X2  both operands split into 2 fp16 terms (x = hi + lo, 22 mantissa bits),
+ *                   3 products hi*hi, hi*lo, lo*hi on v_mfma_f32_16x16x32_f16, fp32 accumulation:
+ *                   fp32-grade (dropped terms <= 2^-22 relative; measured equal to fp32's own
+ *                   reordering noise on this path) with 2/3 of the weight bytes and half the
+ *                   MFMAs of BF16X3.  Operands must stay inside fp16's range (|x| < 65504): true
+ *                   behind this network's GroupNorms; use BF16X3 or F32 for unbounded inputs.
  */
-enum { LGCN_MMA_F32 = 0, LGCN_MMA_BF16X3 = 1, LGCN_MMA_BF16 = 2 };
+enum { LGCN_MMA_F32 = 0, LGCN_MMA_BF16X3 = 1, LGCN_MMA_BF16 = 2, LGCN_MMA_F16X2 = 3 };
 
 /*
  * Weight prepacking.  W is an nn.Linear weight [128, k_real] with row stride
@@ -136,8 +142,8 @@ enum { LGCN_MMA_F32 = 0, LGCN_MMA_BF16X3 = 1, LGCN_MMA_BF16 = 2 };
  *   out[w][q][lane][j] = W[32*w + (lane & 31)][8*q + 4*(lane >> 5) + j]   (fp32)
  * for w < 4, q < k_pad/8, j < 4 (zero for k >= k_real), k_pad % 8 == 0;
  * out holds 128 * k_pad floats.
- * LGCN_MMA_BF16X3 / LGCN_MMA_BF16: k_real = k_pad = 128; 3 (1) bf16 planes
- * (hi, mid, lo of the 3-way split) for v_mfma_f32_16x16x32_bf16:
+ * LGCN_MMA_BF16X3 / LGCN_MMA_F16X2 / LGCN_MMA_BF16: k_real = k_pad = 128; 3 / 2 / 1
+ * 16-bit planes of the split for v_mfma_f32_16x16x32_{bf16,f16}:
  *   out[p][w][s][cb][lane][j] = plane_p(W[32*w + 16*cb + (lane & 15)][32*s + 8*(lane >> 4) + j])
  * p < planes, w < 4, s < 4, cb < 2, j < 8; out holds planes * 32 KiB.
  */

@@ -8,8 +8,8 @@ LIB_PATH = os.path.join(_HERE, "liblgcn.so")
 MAX_REL = 16
 REL_IDENT, REL_CSR, REL_RANGE = 0, 1, 2
 F_GN1, F_RELU1, F_GEMM2, F_GN2, F_RES, F_RELU2 = 1, 2, 4, 8, 16, 32
-MMA_F32, MMA_BF16X3, MMA_BF16 = 0, 1, 2
-MMA_NAMES = {"f32": MMA_F32, "bf16x3": MMA_BF16X3, "bf16": MMA_BF16}
+MMA_F32, MMA_BF16X3, MMA_BF16, MMA_F16X2 = 0, 1, 2, 3
+MMA_NAMES = {"f32": MMA_F32, "bf16x3": MMA_BF16X3, "bf16": MMA_BF16, "f16x2": MMA_F16X2}
 
 
 class LgcnError(RuntimeError):

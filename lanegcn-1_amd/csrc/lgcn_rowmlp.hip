@@ -345,13 +345,13 @@ using namespace lgcn;
 
 extern "C" {
 
-static bool valid_mma(int mma) { return mma == LGCN_MMA_F32 || mma == LGCN_MMA_BF16X3 || mma == LGCN_MMA_BF16; }
+static bool valid_mma(int mma) { return mma >= LGCN_MMA_F32 && mma <= LGCN_MMA_F16X2; }
 
 int64_t lgcn_packed_bytes(int k_pad, int mma) {
     if (!valid_mma(mma) || k_pad < 8 || (k_pad & 7)) return LGCN_EINVAL;
     if (mma == LGCN_MMA_F32) return (int64_t)kC * k_pad * 4;
     if (k_pad != kC) return LGCN_ESHAPE;
-    return (int64_t)(mma == LGCN_MMA_BF16X3 ? 3 : 1) * kC * kC * 2;
+    return (int64_t)(mma == LGCN_MMA_BF16X3 ? 3 : mma == LGCN_MMA_F16X2 ? 2 : 1) * kC * kC * 2;
 }
 
 int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad, int mma, void *out, void *stream) {
@@ -360,7 +360,7 @@ int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad, int mma, voi
     LGCN_CHECK_ALIGN16(out);
     if (mma != LGCN_MMA_F32) {
         if (k_real != kC || k_pad != kC) return LGCN_ESHAPE;
-        return pack_weight_bf(W, ld, mma == LGCN_MMA_BF16X3 ? 3 : 1, out, (hipStream_t)stream);
+        return pack_weight_bf(W, ld, mma, out, (hipStream_t)stream);
     }
     const int total = kC * k_pad;
     hipLaunchKernelGGL(k_pack_weight, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, ld, k_real, k_pad,

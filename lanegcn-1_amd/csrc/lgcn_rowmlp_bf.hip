@@ -1,10 +1,8 @@
-// Split-bf16 variant of the row-block kernels (LGCN_MMA_BF16X3 / LGCN_MMA_BF16).
+// Split-precision variants of the row-block kernels (LGCN_MMA_BF16X3 / LGCN_MMA_F16X2 / LGCN_MMA_BF16).
 //
-// fp32 operands are split into NP bf16 planes (x = hi + mid + lo, 3 x 8 mantissa
-// bits); a K = 128 pass contracts the planes pairwise on
-// v_mfma_f32_16x16x32_bf16 with fp32 accumulation:
-//   NP = 3: lo*hi, hi*lo, mid*mid, mid*hi, hi*mid, hi*hi  (dropped terms <= 2^-24)
-//   NP = 1: hi*hi
+// fp32 operands are split into 16-bit planes (struct Fmt below) and a K = 128 pass contracts the
+// planes pairwise on v_mfma_f32_16x16x32_{bf16,f16} with fp32 accumulation:
+//   bf16x3: x = hi + mid + lo (3 x 8 bits), 6 products    f16x2: x = hi + lo (2 x 11 bits), 3 products
 // Tile = 16*RB rows (RB = 1..4 CSR sub-tiles, picked per launch so that the tile
 // count fits the 256 CUs in as few rounds as possible) x 128 output channels;
 // wave w of the 4 MFMA waves owns channels [32w, 32w+32) as two 16-column
@@ -13,15 +11,75 @@
 // the 4 gather waves exactly like the f32 kernel.
 #include "lgcn_common.hpp"
 #include "lgcn_tile.hpp"
+#include <cstdlib>
+#include <type_traits>
 
 namespace lgcn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kLDB = kC + 8;  // bf16 elements per LDS plane row (272 B)
+constexpr int kLDB = kC + 8;  // 16-bit elements per LDS plane row (272 B)
+
+// Operand formats of the split-precision modes.  A value is stored as NP 16-bit planes
+// (x = p0 + p1 (+ p2), each plane the rounding of the residual left by the previous ones);
+// PROD lists the plane pairs (A plane, B plane) that are multiplied, smallest terms first.
+//   F = 0  LGCN_MMA_BF16X3: 3 bf16 planes (3 x 8 bits), 6 products, dropped terms <= 2^-24
+//   F = 1  LGCN_MMA_F16X2 : 2 fp16 planes (2 x 11 bits), 3 products, dropped terms <= 2^-22
+//          (operands must stay below fp16's 65504: true behind the GroupNorms of this network)
+//   F = 2  LGCN_MMA_BF16  : 1 bf16 plane, 1 product
+template <int F> struct Fmt;
+template <> struct Fmt<0> {
+    static constexpr int NP = 3, NPROD = 6;
+    static constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {
+        const f32x2 v = {a, b};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));   // v_cvt_pk_bf16_f32 (RNE)
+    }
+    static __device__ __forceinline__ f32x2 unpack(uint32_t u) {
+        return f32x2{__builtin_bit_cast(float, u << 16), __builtin_bit_cast(float, u & 0xffff0000u)};
+    }
+    static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Fmt<1> {
+    static constexpr int NP = 2, NPROD = 3;
+    static constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+    static __device__ __forceinline__ uint32_t pack(float a, float b) {
+        const f32x2 v = {a, b};
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2));    // v_cvt_pk_f16_f32 (RNE)
+    }
+    static __device__ __forceinline__ f32x2 unpack(uint32_t u) {
+        return __builtin_convertvector(__builtin_bit_cast(f16x2, u), f32x2);
+    }
+    static __device__ __forceinline__ f32x4 mfma(uint4 a, uint4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    }
+};
+template <> struct Fmt<2> : Fmt<0> {
+    static constexpr int NP = 1, NPROD = 1;
+    static constexpr int PA[1] = {0}, PB[1] = {0};
+};
+
+// Diagnostic build only (-DLGCN_STAMPS, tools/stamps.py): s_memtime stamps of the LaneConv phases go to
+// the buffer passed as out_pre (never to an output); the shipped library contains no stamp.
+#ifdef LGCN_STAMPS
+__device__ __forceinline__ unsigned long long stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define LGCN_STAMP(slot) do { if (lane == 0 && sbuf && (slot) < 64) sbuf[(slot)] = stamp(); } while (0)
+#else
+#define LGCN_STAMP(slot) do { } while (0)
+#endif
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     const f32x2 v = {a, b};
@@ -30,65 +88,61 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-// Split 4 consecutive channels of one row into NP planes and store them.
-template <int NP>
+// Split 4 consecutive channels of one row into the format's planes and store them.
+template <int F>
 __device__ __forceinline__ void split_store(uint16_t *planes, int plane_elems, int row, int col, float4 v) {
     uint16_t *dst = planes + row * kLDB + col;
 #pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const uint32_t a = pack_bf16x2(v.x, v.y), b = pack_bf16x2(v.z, v.w);
+    for (int p = 0; p < Fmt<F>::NP; ++p) {
+        const uint32_t a = Fmt<F>::pack(v.x, v.y), b = Fmt<F>::pack(v.z, v.w);
         *reinterpret_cast<uint2 *>(dst + p * plane_elems) = make_uint2(a, b);
-        if (p + 1 < NP) {  // residual is exact in fp32
-            v.x -= bf16_lo(a); v.y -= bf16_hi(a); v.z -= bf16_lo(b); v.w -= bf16_hi(b);
+        if (p + 1 < Fmt<F>::NP) {  // the residual is exact in fp32
+            const f32x2 ra = Fmt<F>::unpack(a), rb = Fmt<F>::unpack(b);
+            v.x -= ra.x; v.y -= ra.y; v.z -= rb.x; v.w -= rb.y;
         }
     }
 }
 
-template <int RB, int NP>
+template <int RB, int F>
 struct Tile {
     static constexpr int ROWS = 16 * RB;
     static constexpr int PLANE = ROWS * kLDB;            // bf16 elements
-    static constexpr int ABUF_BYTES = NP * PLANE * 2;    // one set of planes
+    static constexpr int ABUF_BYTES = Fmt<F>::NP * PLANE * 2;    // one set of planes
     static constexpr int T_BYTES = ROWS * kLDA * 4;      // fp32 epilogue tile
     static constexpr int SMEM = (2 * ABUF_BYTES > T_BYTES + ABUF_BYTES ? 2 * ABUF_BYTES : T_BYTES + ABUF_BYTES);
 };
 
 // acc[rb][cb] (16 x 16 blocks: rows 16rb.., channels 32w + 16cb..) += A(planes) * W
 // A operand of 16x16x32: lane l holds A[l & 15][k = 8 (l >> 4) + j]; B operand B[k][col = l & 15].
-template <int NP>
-struct BFrag { bf16x8 v[NP][2]; };
+template <int F>
+struct BFrag { uint4 v[Fmt<F>::NP][2]; };
 
-template <int NP>
-__device__ __forceinline__ void load_b(BFrag<NP> &b, const uint4 *__restrict__ Bw, int wave, int lane, int s) {
+template <int F>
+__device__ __forceinline__ void load_b(BFrag<F> &b, const uint4 *__restrict__ Bw, int wave, int lane, int s) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
+    for (int p = 0; p < Fmt<F>::NP; ++p)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb)
-            b.v[p][cb] = __builtin_bit_cast(bf16x8, Bw[((((p * 4 + wave) * 4 + s) * 2 + cb) << 6) + lane]);
+            b.v[p][cb] = Bw[((((p * 4 + wave) * 4 + s) * 2 + cb) << 6) + lane];
 }
 
-template <int RB, int NP>
-__device__ __forceinline__ void kstep(const uint16_t *__restrict__ arow, int s, const BFrag<NP> &b, f32x4 (&acc)[RB][2]) {
-    constexpr int PLANE = Tile<RB, NP>::PLANE;
-    bf16x8 a[NP][RB];
+template <int RB, int F>
+__device__ __forceinline__ void kstep(const uint16_t *__restrict__ arow, int s, const BFrag<F> &b, f32x4 (&acc)[RB][2]) {
+    constexpr int PLANE = Tile<RB, F>::PLANE;
+    uint4 a[Fmt<F>::NP][RB];
 #pragma unroll
-    for (int p = 0; p < NP; ++p)
+    for (int p = 0; p < Fmt<F>::NP; ++p)
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb)
-            a[p][rb] = *reinterpret_cast<const bf16x8 *>(arow + p * PLANE + rb * 16 * kLDB + 32 * s);
+            a[p][rb] = *reinterpret_cast<const uint4 *>(arow + p * PLANE + rb * 16 * kLDB + 32 * s);
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             f32x4 c = acc[rb][cb];
-            if (NP == 3) {  // small terms first
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2][rb], b.v[0][cb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b.v[2][cb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][rb], b.v[1][cb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1][rb], b.v[0][cb], c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b.v[1][cb], c, 0, 0, 0);
-            }
-            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0][rb], b.v[0][cb], c, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < Fmt<F>::NPROD; ++q)   // smallest terms first
+                c = Fmt<F>::mfma(a[Fmt<F>::PA[q]][rb], b.v[Fmt<F>::PB[q]][cb], c);
             acc[rb][cb] = c;
         }
 }
@@ -97,29 +151,54 @@ __device__ __forceinline__ void kstep(const uint16_t *__restrict__ arow, int s, 
 // ring.b[0..2] hold K-steps 0..2 of Bw; step s first issues the load of the step 3 ahead (K-step 3 of
 // this pass for s = 0, K-step s-1 of Bw_next for s >= 1) and then runs its MFMAs, so a fragment has
 // three K-steps of MFMA time to arrive and the stream stays ahead across the per-relation barrier.
-template <int NP>
-struct BRing { BFrag<NP> b[4]; };
+template <int F>
+struct BRing { BFrag<F> b[4]; };
 
-template <int NP>
-__device__ __forceinline__ void ring_prime(BRing<NP> &r, const uint4 *__restrict__ Bw, int wave, int lane) {
-    load_b<NP>(r.b[0], Bw, wave, lane, 0);
-    load_b<NP>(r.b[1], Bw, wave, lane, 1);
-    load_b<NP>(r.b[2], Bw, wave, lane, 2);
+template <int F>
+__device__ __forceinline__ void ring_prime(BRing<F> &r, const uint4 *__restrict__ Bw, int wave, int lane) {
+    load_b<F>(r.b[0], Bw, wave, lane, 0);
+    load_b<F>(r.b[1], Bw, wave, lane, 1);
+    load_b<F>(r.b[2], Bw, wave, lane, 2);
 }
 
-template <int RB, int NP>
+// Shallow variant: two fragment sets, prefetch distance 1 K-step (24 fewer VGPRs at NP = 3, which is
+// what lets two 8-wave workgroups share a CU; the latency is then hidden across workgroups instead).
+template <int F>
+struct BPair { BFrag<F> b[2]; };
+
+template <int F>
+__device__ __forceinline__ void ring_prime(BPair<F> &r, const uint4 *__restrict__ Bw, int wave, int lane) {
+    load_b<F>(r.b[0], Bw, wave, lane, 0);
+}
+
+template <int RB, int F>
 __device__ __forceinline__ void gemm_pass(const uint16_t *__restrict__ A, const uint4 *__restrict__ Bw,
-                                          const uint4 *__restrict__ Bw_next, BRing<NP> &r, int wave, int lane,
+                                          const uint4 *__restrict__ Bw_next, BPair<F> &r, int wave, int lane,
                                           f32x4 (&acc)[RB][2]) {
     const uint16_t *arow = A + (lane & 15) * kLDB + 8 * (lane >> 4);
-    load_b<NP>(r.b[3], Bw, wave, lane, 3);
-    kstep<RB, NP>(arow, 0, r.b[0], acc);
-    if (Bw_next != nullptr) load_b<NP>(r.b[0], Bw_next, wave, lane, 0);
-    kstep<RB, NP>(arow, 1, r.b[1], acc);
-    if (Bw_next != nullptr) load_b<NP>(r.b[1], Bw_next, wave, lane, 1);
-    kstep<RB, NP>(arow, 2, r.b[2], acc);
-    if (Bw_next != nullptr) load_b<NP>(r.b[2], Bw_next, wave, lane, 2);
-    kstep<RB, NP>(arow, 3, r.b[3], acc);
+    load_b<F>(r.b[1], Bw, wave, lane, 1);
+    kstep<RB, F>(arow, 0, r.b[0], acc);
+    load_b<F>(r.b[0], Bw, wave, lane, 2);
+    kstep<RB, F>(arow, 1, r.b[1], acc);
+    load_b<F>(r.b[1], Bw, wave, lane, 3);
+    kstep<RB, F>(arow, 2, r.b[0], acc);
+    if (Bw_next != nullptr) load_b<F>(r.b[0], Bw_next, wave, lane, 0);
+    kstep<RB, F>(arow, 3, r.b[1], acc);
+}
+
+template <int RB, int F>
+__device__ __forceinline__ void gemm_pass(const uint16_t *__restrict__ A, const uint4 *__restrict__ Bw,
+                                          const uint4 *__restrict__ Bw_next, BRing<F> &r, int wave, int lane,
+                                          f32x4 (&acc)[RB][2]) {
+    const uint16_t *arow = A + (lane & 15) * kLDB + 8 * (lane >> 4);
+    load_b<F>(r.b[3], Bw, wave, lane, 3);
+    kstep<RB, F>(arow, 0, r.b[0], acc);
+    if (Bw_next != nullptr) load_b<F>(r.b[0], Bw_next, wave, lane, 0);
+    kstep<RB, F>(arow, 1, r.b[1], acc);
+    if (Bw_next != nullptr) load_b<F>(r.b[1], Bw_next, wave, lane, 1);
+    kstep<RB, F>(arow, 2, r.b[2], acc);
+    if (Bw_next != nullptr) load_b<F>(r.b[2], Bw_next, wave, lane, 2);
+    kstep<RB, F>(arow, 3, r.b[3], acc);
 }
 
 // C/D layout of 16x16: col = lane & 15, row = 4 (lane >> 4) + reg
@@ -143,16 +222,16 @@ __device__ __forceinline__ void acc_zero(f32x4 (&acc)[RB][2]) {
         for (int cb = 0; cb < 2; ++cb) acc[rb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-template <int NP>
+template <int F>
 __device__ __forceinline__ void row_split_store(uint16_t *planes, int plane_elems, int row, int t, const RowVals &r) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) split_store<NP>(planes, plane_elems, row, 4 * (t & 7) + 32 * j, r.v[j]);
+    for (int j = 0; j < 4; ++j) split_store<F>(planes, plane_elems, row, 4 * (t & 7) + 32 * j, r.v[j]);
 }
 
 // ------------------------------------------------------------ packing -----
-__global__ __launch_bounds__(256) void k_pack_weight_bf(const float *__restrict__ W, int ld, int n_planes,
-                                                        uint16_t *__restrict__ out) {
-    // one thread per (w, s, cb, lane): 8 consecutive k of one weight row -> 8 bf16 per plane
+template <int F>
+__global__ __launch_bounds__(256) void k_pack_weight_bf(const float *__restrict__ W, int ld, uint16_t *__restrict__ out) {
+    // one thread per (w, s, cb, lane): 8 consecutive k of one weight row -> 8 elements per plane
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4 * 4 * 2 * 64) return;
     const int lane = i & 63, cb = (i >> 6) & 1, s = (i >> 7) & 3, w = i >> 9;
@@ -160,13 +239,15 @@ __global__ __launch_bounds__(256) void k_pack_weight_bf(const float *__restrict_
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = src[j];
-    for (int p = 0; p < n_planes; ++p) {
+#pragma unroll
+    for (int p = 0; p < Fmt<F>::NP; ++p) {
         uint32_t q[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            q[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
-            v[2 * j] -= bf16_lo(q[j]);
-            v[2 * j + 1] -= bf16_hi(q[j]);
+            q[j] = Fmt<F>::pack(v[2 * j], v[2 * j + 1]);
+            const f32x2 r = Fmt<F>::unpack(q[j]);
+            v[2 * j] -= r.x;
+            v[2 * j + 1] -= r.y;
         }
         uint4 *dst = reinterpret_cast<uint4 *>(out) + ((((p * 4 + w) * 4 + s) * 2 + cb) << 6) + lane;
         *dst = make_uint4(q[0], q[1], q[2], q[3]);
@@ -247,7 +328,7 @@ __device__ __forceinline__ void gather_issue(GReg<RB> &g, const lgcn_agg_mlp_t &
     }
 }
 
-template <int RB, int NP>
+template <int RB, int F>
 __device__ __forceinline__ void gather_finish(GReg<RB> &g, uint16_t *__restrict__ Abuf, const lgcn_agg_mlp_t &p, int ri,
                                               int gt, const TileIdx<RB> &ix) {
     constexpr int IT = GReg<RB>::IT;
@@ -266,13 +347,13 @@ __device__ __forceinline__ void gather_finish(GReg<RB> &g, uint16_t *__restrict_
             s = f4add(f4add(f4add(f4add(s, x[0]), x[1]), x[2]), x[3]);
         }
         for (; j < g.e[it]; ++j) s = f4add(s, src[(int64_t)gather_source<RB>(p, ix, mode, lds_col, g.cadj[it], j) * 32 + l]);
-        split_store<NP>(Abuf, Tile<RB, NP>::PLANE, it * 8 + hw, 4 * l, s);
+        split_store<F>(Abuf, Tile<RB, F>::PLANE, it * 8 + hw, 4 * l, s);
     }
 }
 
-template <int RB, int NP, int KIND>
+template <int RB, int F, int KIND, bool DEEP>
 __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
-    using TL = Tile<RB, NP>;
+    using TL = Tile<RB, F>;
     using IX = TileIdx<RB>;
     constexpr int ROWS = TL::ROWS;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TL::SMEM + 128 + IX::INTS * 4];
@@ -287,6 +368,13 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
     const int tile = xcd_chunk_remap(blockIdx.x, n_tiles);
     const int64_t row0 = (int64_t)tile * ROWS;
     const int64_t n_sub = (p.n_rows + 15) >> 4;
+#ifdef LGCN_STAMPS
+    // wave 0 (MFMA role) -> slots 0..63, wave 4 (gather role) -> slots 64..127 of this block's 128-slot record
+    unsigned long long *sbuf = nullptr;
+    if (KIND == 1 && p.out_pre && (wave == 0 || wave == 4))
+        sbuf = reinterpret_cast<unsigned long long *>(p.out_pre) + (int64_t)blockIdx.x * 128 + (wave == 4 ? 64 : 0);
+    LGCN_STAMP(0);
+#endif
     const int nrc = p.n_rel_csr;
     const bool has_csr = KIND == 1, has_rng = KIND == 0 && p.rowptr != nullptr;
 
@@ -350,6 +438,7 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
     }
     __syncthreads();
     const int nact = __builtin_amdgcn_readfirstlane(act[16]);
+    LGCN_STAMP(1);
 
     // ---- main loop: MFMA waves run pass i on buffer i & 1 while the gather waves fill the other buffer
     // with relation i + 1 (one barrier per relation).  Latency is hidden across workgroups (keep the
@@ -359,18 +448,20 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
     const bool two = (flags & LGCN_F_GEMM2) != 0;
     const int gt = tid - 256;
     auto rel_at = [&](int i) { return __builtin_amdgcn_readfirstlane(act[i]); };
-    BRing<NP> bfrag;
+    typename std::conditional<DEEP, BRing<F>, BPair<F>>::type bfrag;
     if (wave >= 4) {
         if (nact > 0) {
             GReg<RB> g;
             gather_issue<RB>(g, p, rel_at(0), tile, gt, ix);
-            gather_finish<RB, NP>(g, buf0, p, rel_at(0), gt, ix);
+            gather_finish<RB, F>(g, buf0, p, rel_at(0), gt, ix);
         }
     } else {
         const float *w0 = nact > 0 ? p.rel[rel_at(0)].wp : p.wp2;
-        if (w0 != nullptr) ring_prime<NP>(bfrag, reinterpret_cast<const uint4 *>(w0), wave, lane);
+        if (w0 != nullptr) ring_prime<F>(bfrag, reinterpret_cast<const uint4 *>(w0), wave, lane);
     }
+    LGCN_STAMP(2);
     __syncthreads();
+    LGCN_STAMP(3);
 
     f32x4 acc[RB][2];
     acc_zero<RB>(acc);
@@ -380,15 +471,17 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
         if (wave < 4) {
             if (!(flags & (1 << 9))) {   // timing-only ablation bit (tools/bench_agg.py): skip the MFMA passes
             const float *wn = i + 1 < nact ? p.rel[rel_at(i + 1)].wp : (two ? p.wp2 : nullptr);
-            gemm_pass<RB, NP>(cur, reinterpret_cast<const uint4 *>(p.rel[rel_at(i)].wp),
+            gemm_pass<RB, F>(cur, reinterpret_cast<const uint4 *>(p.rel[rel_at(i)].wp),
                               reinterpret_cast<const uint4 *>(wn), bfrag, wave, lane, acc);
             }
         } else if (i + 1 < nact && !(flags & (1 << 8))) {   // ablation bit: skip the in-loop gathers
             GReg<RB> g;
             gather_issue<RB>(g, p, rel_at(i + 1), tile, gt, ix);
-            gather_finish<RB, NP>(g, nxt, p, rel_at(i + 1), gt, ix);
+            gather_finish<RB, F>(g, nxt, p, rel_at(i + 1), gt, ix);
         }
+        LGCN_STAMP(4 + 2 * i);       // own work of pass i done
         __syncthreads();
+        LGCN_STAMP(5 + 2 * i);       // barrier passed
     }
 
     if (wave < 4) {
@@ -410,7 +503,9 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
         }
         acc_store<RB>(T, acc, lane, wave);
     }
+    LGCN_STAMP(40);
     __syncthreads();
+    LGCN_STAMP(41);
 
     if (tid < 256) {
 #pragma unroll
@@ -420,23 +515,29 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
                 const int64_t n = row0 + row;
                 const bool live = n < p.n_rows;
                 RowVals r = row_load(T + c0 * kLDA, tid);
+#ifndef LGCN_STAMPS
                 if (live && p.out_pre) row_store_global(p.out_pre + n * kC, tid, r);
+#endif
                 if (flags & LGCN_F_GN1) row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
                 if (!two && live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
                 if (flags & LGCN_F_RELU1) row_relu(r);
-                if (two) row_split_store<NP>(Yp, TL::PLANE, row, tid, r);
+                if (two) row_split_store<F>(Yp, TL::PLANE, row, tid, r);
                 else if (live) row_store_global(p.out + n * kC, tid, r);
             }
         }
     }
     if (!two) return;
+    LGCN_STAMP(42);
     __syncthreads();
+    LGCN_STAMP(43);
     if (wave < 4) {
         acc_zero<RB>(acc);
-        gemm_pass<RB, NP>(Yp, reinterpret_cast<const uint4 *>(p.wp2), nullptr, bfrag, wave, lane, acc);
+        gemm_pass<RB, F>(Yp, reinterpret_cast<const uint4 *>(p.wp2), nullptr, bfrag, wave, lane, acc);
         acc_store<RB>(T, acc, lane, wave);   // T and Yp are disjoint; T's readers passed the barrier above
     }
+    LGCN_STAMP(44);
     __syncthreads();
+    LGCN_STAMP(45);
     if (tid < 256) {
 #pragma unroll
         for (int c0 = 0; c0 < ROWS; c0 += 32) {
@@ -452,11 +553,12 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
             }
         }
     }
+    LGCN_STAMP(46);
 }
 
 // ------------------------------------------------------- shared pieces -----
 // h1[row][c] = ReLU(w1[c][0] x + w1[c][1] y + b1[c]) for the thread's 16 channels, split into planes
-template <int NP>
+template <int F>
 __device__ __forceinline__ void lin2_relu_split(uint16_t *planes, int plane_elems, int row, int t, float x, float y,
                                                 const float *__restrict__ w1, const float *__restrict__ b1) {
     const int c0 = 4 * (t & 7);
@@ -471,13 +573,13 @@ __device__ __forceinline__ void lin2_relu_split(uint16_t *planes, int plane_elem
         o.y = fmaxf(x * wa.z + y * wa.w + bb.y, 0.f);
         o.z = fmaxf(x * wb.x + y * wb.y + bb.z, 0.f);
         o.w = fmaxf(x * wb.z + y * wb.w + bb.w, 0.f);
-        split_store<NP>(planes, plane_elems, row, c, o);
+        split_store<F>(planes, plane_elems, row, c, o);
     }
 }
 
-template <int RB, int NP>
+template <int RB, int F>
 __global__ __launch_bounds__(256) void k_mapnet_input_bf(const InputParams p, int n_tiles) {
-    using TL = Tile<RB, NP>;
+    using TL = Tile<RB, F>;
     constexpr int ROWS = TL::ROWS;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TL::ABUF_BYTES + TL::T_BYTES];
     uint16_t *A = reinterpret_cast<uint16_t *>(smem);
@@ -499,15 +601,15 @@ __global__ __launch_bounds__(256) void k_mapnet_input_bf(const InputParams p, in
             if (row < ROWS) {
                 float2 v = make_float2(0.f, 0.f);
                 if (row0 + row < p.n_rows) v = xy[row0 + row];
-                lin2_relu_split<NP>(A, TL::PLANE, row, tid, v.x, v.y, w1, b1);
+                lin2_relu_split<F>(A, TL::PLANE, row, tid, v.x, v.y, w1, b1);
             }
         }
         __syncthreads();
         acc_zero<RB>(acc);
         {
-            BRing<NP> bf;
-            ring_prime<NP>(bf, reinterpret_cast<const uint4 *>(wp), wave, lane);
-            gemm_pass<RB, NP>(A, reinterpret_cast<const uint4 *>(wp), nullptr, bf, wave, lane, acc);
+            BPair<F> bf;
+            ring_prime<F>(bf, reinterpret_cast<const uint4 *>(wp), wave, lane);
+            gemm_pass<RB, F>(A, reinterpret_cast<const uint4 *>(wp), nullptr, bf, wave, lane, acc);
         }
         acc_store<RB>(T, acc, lane, wave);
         __syncthreads();
@@ -531,9 +633,9 @@ __global__ __launch_bounds__(256) void k_mapnet_input_bf(const InputParams p, in
     }
 }
 
-template <int RB, int NP>
+template <int RB, int F>
 __global__ __launch_bounds__(256) void k_att_pairs_bf(const PairParams p) {
-    using TL = Tile<RB, NP>;
+    using TL = Tile<RB, F>;
     constexpr int ROWS = TL::ROWS;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TL::ABUF_BYTES + TL::T_BYTES];
     uint16_t *A = reinterpret_cast<uint16_t *>(smem);
@@ -544,8 +646,8 @@ __global__ __launch_bounds__(256) void k_att_pairs_bf(const PairParams p) {
     const int64_t n_tiles = (P + ROWS - 1) / ROWS;
     f32x4 acc[RB][2];
     const uint4 *wd2 = reinterpret_cast<const uint4 *>(p.wpd2), *wc0 = reinterpret_cast<const uint4 *>(p.wpc0e);
-    BRing<NP> bf;
-    if ((int64_t)blockIdx.x < n_tiles) ring_prime<NP>(bf, wd2, wave, lane);
+    BPair<F> bf;
+    if ((int64_t)blockIdx.x < n_tiles) ring_prime<F>(bf, wd2, wave, lane);
 
     for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int64_t pr0 = tile * ROWS;
@@ -559,12 +661,12 @@ __global__ __launch_bounds__(256) void k_att_pairs_bf(const PairParams p) {
                     const float2 c = reinterpret_cast<const float2 *>(p.ctx_ctrs)[p.wi[pr0 + row]];
                     dx = a.x - c.x; dy = a.y - c.y;
                 }
-                lin2_relu_split<NP>(A, TL::PLANE, row, tid, dx, dy, p.wd0, p.bd0);
+                lin2_relu_split<F>(A, TL::PLANE, row, tid, dx, dy, p.wd0, p.bd0);
             }
         }
         __syncthreads();
         acc_zero<RB>(acc);
-        gemm_pass<RB, NP>(A, wd2, wc0, bf, wave, lane, acc);
+        gemm_pass<RB, F>(A, wd2, wc0, bf, wave, lane, acc);
         acc_store<RB>(T, acc, lane, wave);
         __syncthreads();   // all waves done reading A; T complete
 #pragma unroll
@@ -574,12 +676,12 @@ __global__ __launch_bounds__(256) void k_att_pairs_bf(const PairParams p) {
                 RowVals r = row_load(T + c0 * kLDA, tid);
                 row_gn(r, tid, p.gd, p.btd, p.eps);
                 row_relu(r);
-                row_split_store<NP>(A, TL::PLANE, row, tid, r);
+                row_split_store<F>(A, TL::PLANE, row, tid, r);
             }
         }
         __syncthreads();
         acc_zero<RB>(acc);
-        gemm_pass<RB, NP>(A, wc0, wd2, bf, wave, lane, acc);   // prefetches the next tile's first fragments
+        gemm_pass<RB, F>(A, wc0, wd2, bf, wave, lane, acc);   // prefetches the next tile's first fragments
         acc_store<RB>(T, acc, lane, wave);   // T's readers (previous row phase) passed the barrier above
         __syncthreads();
 #pragma unroll
@@ -616,13 +718,16 @@ static int cu_count() {
     return n;
 }
 
-// 16-row blocks per tile: fewest rounds over the CUs, then the tallest tile (weight reuse)
-static int pick_rb(int64_t n_rows, int wgs_per_cu) {
+// 16-row blocks per tile.  Tiles of <= 32 rows (<= 128 VGPRs, <= 63 KB LDS) run two workgroups per CU,
+// taller ones one; pick the height with the fewest rounds x height, the taller on ties (weight reuse:
+// every tile streams the full weight set through L2 once).  Measured on S2 (10,368 rows): 32-row tiles
+// beat 48-row ones by 9 % alone and by 25 % with four forwards in flight.
+static int pick_rb(int64_t n_rows, int /*unused*/) {
     const int64_t n_sub = (n_rows + 15) / 16;
-    const int64_t slots = (int64_t)cu_count() * wgs_per_cu;
     int best = 1;
     int64_t best_cost = -1;
     for (int rb = 1; rb <= 4; ++rb) {
+        const int64_t slots = (int64_t)cu_count() * (rb <= 2 ? 2 : 1);
         const int64_t tiles = (n_sub + rb - 1) / rb;
         const int64_t cost = ((tiles + slots - 1) / slots) * rb;
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = rb; }
@@ -630,13 +735,20 @@ static int pick_rb(int64_t n_rows, int wgs_per_cu) {
     return best;
 }
 
-template <int NP>
+// Tuning knobs for experiments (read once): LGCN_RB forces the tile height, LGCN_RING=1|3 the weight
+// prefetch distance.  Defaults: height by pick_rb, distance 1.
+static int env_int(const char *name, int dflt) {
+    const char *v = std::getenv(name);
+    return v && *v ? std::atoi(v) : dflt;
+}
+
+template <int F, bool DEEP>
 static void launch_agg(const lgcn_agg_mlp_t &p, int rb, bool lane_conv, hipStream_t st) {
     const int rows = 16 * rb;
     const int n_tiles = (int)((p.n_rows + rows - 1) / rows);
-#define LGCN_AGG(RB_)                                                                                          \
-    if (lane_conv) hipLaunchKernelGGL((k_agg_mlp_bf<RB_, NP, 1>), dim3(n_tiles), dim3(512), 0, st, p, n_tiles); \
-    else hipLaunchKernelGGL((k_agg_mlp_bf<RB_, NP, 0>), dim3(n_tiles), dim3(512), 0, st, p, n_tiles)
+#define LGCN_AGG(RB_)                                                                                                \
+    if (lane_conv) hipLaunchKernelGGL((k_agg_mlp_bf<RB_, F, 1, DEEP>), dim3(n_tiles), dim3(512), 0, st, p, n_tiles); \
+    else hipLaunchKernelGGL((k_agg_mlp_bf<RB_, F, 0, DEEP>), dim3(n_tiles), dim3(512), 0, st, p, n_tiles)
     switch (rb) {
         case 1: LGCN_AGG(1); break;
         case 2: LGCN_AGG(2); break;
@@ -646,24 +758,34 @@ static void launch_agg(const lgcn_agg_mlp_t &p, int rb, bool lane_conv, hipStrea
 #undef LGCN_AGG
 }
 
+// LGCN_MMA_* -> format id of Fmt<>
+static int fmt_of(int mma) { return mma == LGCN_MMA_BF16X3 ? 0 : mma == LGCN_MMA_F16X2 ? 1 : 2; }
+
 int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st) {
+    static const int force_rb = env_int("LGCN_RB", 0), ring = env_int("LGCN_RING", 1);
     int rb = p.tile_rb;
     if (rb < 0 || rb > 4) return LGCN_EINVAL;
-    if (rb == 0) rb = pick_rb(p.n_rows, 1);
-    if (p.mma == LGCN_MMA_BF16X3) launch_agg<3>(p, rb, lane_conv, st);
-    else launch_agg<1>(p, rb, lane_conv, st);
+    if (rb == 0) rb = force_rb >= 1 && force_rb <= 4 ? force_rb : pick_rb(p.n_rows, 1);
+    const bool deep = ring >= 3;
+    switch (fmt_of(p.mma)) {
+        case 0: if (deep) launch_agg<0, true>(p, rb, lane_conv, st); else launch_agg<0, false>(p, rb, lane_conv, st); break;
+        case 1: if (deep) launch_agg<1, true>(p, rb, lane_conv, st); else launch_agg<1, false>(p, rb, lane_conv, st); break;
+        default: if (deep) launch_agg<2, true>(p, rb, lane_conv, st); else launch_agg<2, false>(p, rb, lane_conv, st); break;
+    }
     return launch_status();
 }
 
 int mapnet_input_bf(const InputParams &p, int mma, hipStream_t st) {
     const int rb = pick_rb(p.n_rows, 2);
     const int n_tiles = (int)((p.n_rows + 16 * rb - 1) / (16 * rb));
-#define LGCN_IN(RB_, NP_) hipLaunchKernelGGL((k_mapnet_input_bf<RB_, NP_>), dim3(n_tiles), dim3(256), 0, st, p, n_tiles)
-    if (mma == LGCN_MMA_BF16X3) {
-        switch (rb) { case 1: LGCN_IN(1, 3); break; case 2: LGCN_IN(2, 3); break; case 3: LGCN_IN(3, 3); break; default: LGCN_IN(4, 3); }
-    } else {
-        switch (rb) { case 1: LGCN_IN(1, 1); break; case 2: LGCN_IN(2, 1); break; case 3: LGCN_IN(3, 1); break; default: LGCN_IN(4, 1); }
+#define LGCN_IN(RB_, F_) hipLaunchKernelGGL((k_mapnet_input_bf<RB_, F_>), dim3(n_tiles), dim3(256), 0, st, p, n_tiles)
+#define LGCN_IN_RB(F_) switch (rb) { case 1: LGCN_IN(1, F_); break; case 2: LGCN_IN(2, F_); break; case 3: LGCN_IN(3, F_); break; default: LGCN_IN(4, F_); }
+    switch (fmt_of(mma)) {
+        case 0: LGCN_IN_RB(0); break;
+        case 1: LGCN_IN_RB(1); break;
+        default: LGCN_IN_RB(2); break;
     }
+#undef LGCN_IN_RB
 #undef LGCN_IN
     return launch_status();
 }
@@ -674,13 +796,21 @@ int att_pairs_bf(const PairParams &p, int mma, hipStream_t st) {
     const int64_t tiles = (p.cap + 31) / 32;
     const int64_t slots = (int64_t)cu_count() * 3;
     const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
-    if (mma == LGCN_MMA_BF16X3) hipLaunchKernelGGL((k_att_pairs_bf<2, 3>), dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((k_att_pairs_bf<2, 1>), dim3(grid), dim3(256), 0, st, p);
+    switch (fmt_of(mma)) {
+        case 0: hipLaunchKernelGGL((k_att_pairs_bf<2, 0>), dim3(grid), dim3(256), 0, st, p); break;
+        case 1: hipLaunchKernelGGL((k_att_pairs_bf<2, 1>), dim3(grid), dim3(256), 0, st, p); break;
+        default: hipLaunchKernelGGL((k_att_pairs_bf<2, 2>), dim3(grid), dim3(256), 0, st, p); break;
+    }
     return launch_status();
 }
 
-int pack_weight_bf(const float *W, int ld, int n_planes, void *out, hipStream_t st) {
-    hipLaunchKernelGGL(k_pack_weight_bf, dim3(8), dim3(256), 0, st, W, ld, n_planes, reinterpret_cast<uint16_t *>(out));
+int pack_weight_bf(const float *W, int ld, int mma, void *out, hipStream_t st) {
+    uint16_t *o = reinterpret_cast<uint16_t *>(out);
+    switch (fmt_of(mma)) {
+        case 0: hipLaunchKernelGGL((k_pack_weight_bf<0>), dim3(8), dim3(256), 0, st, W, ld, o); break;
+        case 1: hipLaunchKernelGGL((k_pack_weight_bf<1>), dim3(8), dim3(256), 0, st, W, ld, o); break;
+        default: hipLaunchKernelGGL((k_pack_weight_bf<2>), dim3(8), dim3(256), 0, st, W, ld, o); break;
+    }
     return launch_status();
 }
 

@@ -19,12 +19,13 @@ EPS = 1e-5
 # How the 128-d contractions run on the matrix cores (include/lgcn.h, LGCN_MMA_*):
 #   "f32"    exact fp32 fma chain (v_mfma_f32_32x32x2_f32)
 #   "bf16x3" 3-way bf16 split, 6 products, fp32 accumulate: fp32-grade, 2.67x the f32 MFMA rate
+#   "f16x2"  2-way fp16 split, 3 products, fp32 accumulate: fp32-grade (operands < 65504), 5.3x the f32 rate
 #   "bf16"   single bf16 product (BASELINE config "bf16"; not within 1e-4)
-_mma = L.MMA_NAMES[os.environ.get("LGCN_MMA", "bf16x3")]
+_mma = L.MMA_NAMES[os.environ.get("LGCN_MMA", "f16x2")]
 
 
 def set_mma(name: str):
-    """Select the matrix-core mode for subsequent launches ("f32" | "bf16x3" | "bf16")."""
+    """Select the matrix-core mode for subsequent launches ("f32" | "bf16x3" | "f16x2" | "bf16")."""
     global _mma
     _mma = L.MMA_NAMES[name]
 

@@ -22,10 +22,10 @@ def hip():
     return M, ops
 
 
-@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+@pytest.fixture(autouse=True, params=["f32", "bf16x3", "f16x2"])
 def mma_mode(request, hip):
-    """Every test runs on both matrix-core modes that claim fp32 parity: the exact f32 MFMA chain and
-    the 3-way-split bf16 MFMA (6 products).  Same 1e-4 bar for both."""
+    """Every test runs on all matrix-core modes that claim fp32 parity: the exact f32 MFMA chain, the
+    3-way bf16 split (6 products) and the 2-way fp16 split (3 products).  Same 1e-4 bar for all."""
     _, ops = hip
     prev = ops.get_mma()
     ops.set_mma(request.param)

@@ -52,6 +52,7 @@ def test_size_helpers(lib):
     assert l.lgcn_csr_rowptr_elems(33, 14) == 3 * 14 * 16 + 1
     assert l.lgcn_packed_bytes(128, 0) == 65536 and l.lgcn_packed_bytes(136, 0) == 128 * 136 * 4
     assert l.lgcn_packed_bytes(128, 1) == 3 * 32768 and l.lgcn_packed_bytes(128, 2) == 32768
+    assert l.lgcn_packed_bytes(128, 3) == 2 * 32768
     assert l.lgcn_packed_bytes(136, 1) < 0 and l.lgcn_packed_bytes(128, 9) < 0
     assert l.lgcn_csr_rowptr_elems(10, 17) < 0
     assert l.lgcn_csr_ws_elems(10368, 14) > l.lgcn_csr_rowptr_elems(10368, 14)
@@ -92,7 +93,7 @@ def test_bad_arguments_are_refused_without_launching(lib):
     assert l.lgcn_pairs_build(None, None, None, None, 0, 0, 0, 1.0, 1, None, None, 0, None, None, None, None) == EINVAL
     assert l.lgcn_att_pairs(*([None] * 5), -1, *([None] * 10), 1e-5, 0, None, None) == EINVAL
     assert l.lgcn_att_pairs(*([None] * 5), 0, *([None] * 10), 1e-5, 0, None, None) == 0
-    assert l.lgcn_att_pairs(*([None] * 5), 0, *([None] * 10), 1e-5, 3, None, None) == EINVAL
+    assert l.lgcn_att_pairs(*([None] * 5), 0, *([None] * 10), 1e-5, 9, None, None) == EINVAL
     assert l.lgcn_mapnet_input(None, None, 5, *([None] * 10), 1e-5, 1, None, None) == EINVAL
 
 
