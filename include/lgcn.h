@@ -150,6 +150,9 @@ enum { LGCN_MMA_F32 = 0, LGCN_MMA_BF16X3 = 1, LGCN_MMA_BF16 = 2, LGCN_MMA_F16X2 
 int64_t lgcn_packed_bytes(int k_pad, int mma);
 int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad, int mma,
                      void *out, void *stream);
+/* Same, for the TRANSPOSE of a square [128,128] weight (W[k][j] read in place of W[j][k]): the
+ * backward of y = x W^T is dx = dy W, i.e. a Linear whose weight is W^T. */
+int lgcn_pack_weight_t(const float *W, int ld, int mma, void *out, void *stream);
 
 /* One relation of an aggregate-GEMM stage (see lgcn_agg_mlp). */
 typedef struct {
@@ -190,7 +193,9 @@ typedef struct {
     const float *gn2_g, *gn2_b;
     const float *res;        /* [N,128] residual                           */
     float *out;              /* [N,128]                                    */
-    float *out_pre;          /* optional [N,128]: stage-1 pre-GN1 sums     */
+    float *out_pre;          /* optional [N,128]: stage-1 sums T (pre-GN1)  (saved for backward) */
+    float *out_mid;          /* optional [N,128]: Y = act(GN1(T)), the stage-2 operand          */
+    float *out_pre2;         /* optional [N,128]: Z = Y W2^T (pre-GN2)                          */
 } lgcn_agg_mlp_t;
 
 /*
@@ -236,6 +241,61 @@ int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs,
                    const float *wpc0e, const float *U, const float *V,
                    const float *gc, const float *btc,
                    float eps, int mma, float *m, void *stream);
+
+/* ------------------------------------------------------------------ */
+/* Backward building blocks (fp32; the row-GEMMs of the backward are     */
+/* lgcn_agg_mlp launches on transposed plans / transposed weights)       */
+/* ------------------------------------------------------------------ */
+
+/*
+ * Backward of  y = [ReLU]( GroupNorm(1,128)(x) [+ res] )  for row-major [n_rows,128] tensors
+ * (layers.py:73-87 and the norm/relu/residual lines of lanegcn.py:356-361, 704-709):
+ *   g  = dy * (post > 0)            when post != NULL (post = the forward output after ReLU)
+ *   dx = rstd * (g*gamma - mean(g*gamma) - xhat * mean(g*gamma*xhat)),  xhat = (x - mean) * rstd
+ *   dgamma = sum_rows g * xhat,  dbeta = sum_rows g
+ * dg_out (optional, [n_rows,128]) receives g itself (the gradient that flows into `res`).
+ * gamma == NULL: no normalisation (dx = g), used for plain ReLU masks.
+ * dgamma / dbeta: [128] outputs; part: workspace of 2 * ceil(n_rows/32) * 128 floats.
+ * Deterministic (two-level tree, no atomics).
+ */
+int lgcn_gn_bwd(const float *dy, const float *x, const float *post, const float *gamma,
+                int64_t n_rows, float eps, float *dx, float *dg_out,
+                float *dgamma, float *dbeta, float *part, void *stream);
+
+/*
+ * Weight gradients of an aggregate-GEMM stage T = sum_r (G_r src_r) W_r^T:
+ *   dW[r] = dT^T (G_r src_r)      [128,128] per relation, fp32 (f32-input MFMA, exact fma chain)
+ * The relations (src, mode, ridx), rowptr/col/n_rel_csr and n_rows are read from *p exactly as
+ * lgcn_agg_mlp reads them (wp and the epilogue fields are ignored).
+ * dW: [n_rel,128,128]; part: workspace of n_rel * n_chunks * 128*128 floats, n_chunks in 1..64.
+ */
+int lgcn_wgrad(const lgcn_agg_mlp_t *p_host, const float *dT, float *dW, float *part,
+               int n_chunks, void *stream);
+
+/*
+ * Forward of  out = [ReLU]( GroupNorm(1,128)(x) [+ res] )  as a stand-alone row kernel (the fused
+ * kernels do this in their epilogues; the differentiable per-pair composition needs it alone).
+ * gamma == NULL: no normalisation.  relu != 0 applies the ReLU.
+ */
+int lgcn_gn_fwd(const float *x, const float *gamma, const float *beta, const float *res,
+                int64_t n_rows, float eps, int relu, float *out, void *stream);
+
+/*
+ * out[n] = sum_{j in [rowptr[n], rowptr[n+1])} src[col ? col[j] : j]   for n < n_rows (rows of 128 floats,
+ * fixed summation order).  col == NULL: contiguous segments (index_add_ by a sorted index, lanegcn.py:703);
+ * with col: a plain CSR (transposes of gathers in the backward).
+ */
+int lgcn_gather_sum(const float *src, const int32_t *rowptr, const int32_t *col, int64_t n_rows,
+                    float *out, void *stream);
+
+/* out[p] = c[p] + U[hi[p]] + V[wi[p]] for p < *n (device count, clamped to cap)  (lanegcn.py:696-699 after
+ * hoisting the row-wise Linears out of the pair loop). */
+int lgcn_pair_add(const float *c, const float *U, const int32_t *hi, const float *V, const int32_t *wi,
+                  const int32_t *n_dev, int64_t cap, float *out, void *stream);
+
+/* out[i] = src[idx[i]] for i < *n (device count, clamped to cap); rows of 128 floats. */
+int lgcn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev, int64_t cap,
+                     float *out, void *stream);
 
 #ifdef __cplusplus
 }

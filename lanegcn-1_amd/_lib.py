@@ -30,6 +30,7 @@ class AggMlp(C.Structure):
         ("gn1_g", C.c_void_p), ("gn1_b", C.c_void_p),
         ("wp2", C.c_void_p), ("gn2_g", C.c_void_p), ("gn2_b", C.c_void_p),
         ("res", C.c_void_p), ("out", C.c_void_p), ("out_pre", C.c_void_p),
+        ("out_mid", C.c_void_p), ("out_pre2", C.c_void_p),
     ]
 
 
@@ -48,7 +49,14 @@ SIGNATURES = {
     "lgcn_widen_i32": (C.c_int, [_P, _P, _L, _P, _P]),
     "lgcn_packed_bytes": (C.c_int64, [_I, _I]),
     "lgcn_pack_weight": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
+    "lgcn_pack_weight_t": (C.c_int, [_P, _I, _I, _P, _P]),
     "lgcn_agg_mlp": (C.c_int, [C.POINTER(AggMlp), _P]),
+    "lgcn_gn_bwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _P, _P]),
+    "lgcn_gn_fwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _I, _P, _P]),
+    "lgcn_wgrad": (C.c_int, [C.POINTER(AggMlp), _P, _P, _P, _I, _P]),
+    "lgcn_gather_rows": (C.c_int, [_P, _P, _P, _L, _P, _P]),
+    "lgcn_gather_sum": (C.c_int, [_P, _P, _P, _L, _P, _P]),
+    "lgcn_pair_add": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _P, _P]),
     "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
     "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
 }

@@ -1,0 +1,253 @@
+// Backward building blocks of the LaneGCN hot path (fp32): GroupNorm/ReLU backward rows, the
+// deterministic column reductions behind dgamma/dbeta, and a row gather.  The row-GEMMs of the
+// backward are lgcn_agg_mlp launches (transposed plan / transposed weights); the weight
+// gradients live next to the forward gather code in lgcn_rowmlp.hip (lgcn_wgrad).
+#include "lgcn_common.hpp"
+#include "lgcn_tile.hpp"
+
+namespace lgcn {
+
+// One block = 32 rows, thread (row = t >> 3, sub = t & 7) owns channels 4*sub + 32*j + {0..3}.
+__global__ __launch_bounds__(256) void k_gn_bwd(const float *__restrict__ dy, const float *__restrict__ x,
+                                                const float *__restrict__ post, const float *__restrict__ gamma,
+                                                int64_t n_rows, float eps, float *__restrict__ dx,
+                                                float *__restrict__ dg_out, float *__restrict__ part) {
+    __shared__ float red[2][32][kC + 4];
+    const int t = threadIdx.x;
+    const int64_t n = (int64_t)blockIdx.x * 32 + (t >> 3);
+    const bool live = n < n_rows;
+    const int c0 = 4 * (t & 7);
+    RowVals g, xh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { g.v[j] = make_float4(0.f, 0.f, 0.f, 0.f); xh.v[j] = g.v[j]; }
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            g.v[j] = *reinterpret_cast<const float4 *>(dy + n * kC + c0 + 32 * j);
+            if (post) {
+                const float4 o = *reinterpret_cast<const float4 *>(post + n * kC + c0 + 32 * j);
+                g.v[j].x = o.x > 0.f ? g.v[j].x : 0.f; g.v[j].y = o.y > 0.f ? g.v[j].y : 0.f;
+                g.v[j].z = o.z > 0.f ? g.v[j].z : 0.f; g.v[j].w = o.w > 0.f ? g.v[j].w : 0.f;
+            }
+            if (dg_out) *reinterpret_cast<float4 *>(dg_out + n * kC + c0 + 32 * j) = g.v[j];
+        }
+    }
+    if (gamma == nullptr) {   // plain mask
+        if (live)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(dx + n * kC + c0 + 32 * j) = g.v[j];
+        return;
+    }
+    float rstd = 0.f;
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xh.v[j] = *reinterpret_cast<const float4 *>(x + n * kC + c0 + 32 * j);
+    }
+    {   // xhat = (x - mean) * rstd, two-pass like the forward
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += (xh.v[j].x + xh.v[j].y) + (xh.v[j].z + xh.v[j].w);
+        const float mean = sum8(s) * (1.0f / kC);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            xh.v[j].x -= mean; xh.v[j].y -= mean; xh.v[j].z -= mean; xh.v[j].w -= mean;
+            q += (xh.v[j].x * xh.v[j].x + xh.v[j].y * xh.v[j].y) + (xh.v[j].z * xh.v[j].z + xh.v[j].w * xh.v[j].w);
+        }
+        rstd = 1.0f / sqrtf(sum8(q) * (1.0f / kC) + eps);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { xh.v[j].x *= rstd; xh.v[j].y *= rstd; xh.v[j].z *= rstd; xh.v[j].w *= rstd; }
+    }
+    float m1 = 0.f, m2 = 0.f;
+    RowVals d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 gm = *reinterpret_cast<const float4 *>(gamma + c0 + 32 * j);
+        d.v[j] = make_float4(g.v[j].x * gm.x, g.v[j].y * gm.y, g.v[j].z * gm.z, g.v[j].w * gm.w);
+        m1 += (d.v[j].x + d.v[j].y) + (d.v[j].z + d.v[j].w);
+        m2 += (d.v[j].x * xh.v[j].x + d.v[j].y * xh.v[j].y) + (d.v[j].z * xh.v[j].z + d.v[j].w * xh.v[j].w);
+    }
+    m1 = sum8(m1) * (1.0f / kC);
+    m2 = sum8(m2) * (1.0f / kC);
+    if (live) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 o;
+            o.x = rstd * (d.v[j].x - m1 - xh.v[j].x * m2); o.y = rstd * (d.v[j].y - m1 - xh.v[j].y * m2);
+            o.z = rstd * (d.v[j].z - m1 - xh.v[j].z * m2); o.w = rstd * (d.v[j].w - m1 - xh.v[j].w * m2);
+            *reinterpret_cast<float4 *>(dx + n * kC + c0 + 32 * j) = o;
+        }
+    }
+    // per-block partial dgamma / dbeta: sum over the block's 32 rows (fixed order)
+    const int row = t >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float *a = &red[0][row][c0 + 32 * j], *b = &red[1][row][c0 + 32 * j];
+        a[0] = g.v[j].x * xh.v[j].x; a[1] = g.v[j].y * xh.v[j].y; a[2] = g.v[j].z * xh.v[j].z; a[3] = g.v[j].w * xh.v[j].w;
+        b[0] = g.v[j].x; b[1] = g.v[j].y; b[2] = g.v[j].z; b[3] = g.v[j].w;
+    }
+    __syncthreads();
+    {
+        const int which = t >> 7, c = t & 127;
+        float s = 0.f;
+#pragma unroll 8
+        for (int rr = 0; rr < 32; ++rr) s += red[which][rr][c];
+        part[((int64_t)which * gridDim.x + blockIdx.x) * kC + c] = s;
+    }
+}
+
+// out[which][c] = sum_b part[which][b][c]   (2 x 128 outputs, one block of 256 threads, fixed order)
+__global__ __launch_bounds__(256) void k_colsum_parts(const float *__restrict__ part, int n_blocks,
+                                                      float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    const int which = threadIdx.x >> 7, c = threadIdx.x & 127;
+    const float *p = part + (int64_t)which * n_blocks * kC + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int b = 0;
+    for (; b + 3 < n_blocks; b += 4) {
+        s0 += p[(int64_t)b * kC]; s1 += p[(int64_t)(b + 1) * kC]; s2 += p[(int64_t)(b + 2) * kC]; s3 += p[(int64_t)(b + 3) * kC];
+    }
+    for (; b < n_blocks; ++b) s0 += p[(int64_t)b * kC];
+    float *o = which == 0 ? dgamma : dbeta;
+    if (o) o[c] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ __launch_bounds__(256) void k_gather_rows(const float4 *__restrict__ src, const int32_t *__restrict__ idx,
+                                                     const int32_t *__restrict__ n_dev, int64_t cap,
+                                                     float4 *__restrict__ out) {
+    int64_t n = *n_dev;
+    if (n < 0 || n > cap) n = cap;
+    const int l = threadIdx.x & 31;
+    for (int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); i < n; i += (int64_t)gridDim.x * 8)
+        out[i * 32 + l] = src[(int64_t)idx[i] * 32 + l];
+}
+
+__global__ __launch_bounds__(256) void k_gn_fwd(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                const float *__restrict__ beta, const float *__restrict__ res,
+                                                int64_t n_rows, float eps, int relu, float *__restrict__ out) {
+    const int t = threadIdx.x;
+    const int64_t n = (int64_t)blockIdx.x * 32 + (t >> 3);
+    const bool live = n < n_rows;
+    const int c0 = 4 * (t & 7);
+    RowVals r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        r.v[j] = live ? *reinterpret_cast<const float4 *>(x + n * kC + c0 + 32 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gamma) row_gn(r, t, gamma, beta, eps);
+    if (live && res) row_add_global(r, res + n * kC, t);
+    if (relu) row_relu(r);
+    if (live) row_store_global(out + n * kC, t, r);
+}
+
+// one half-wave per output row, float4 per lane
+__global__ __launch_bounds__(256) void k_gather_sum(const float4 *__restrict__ src, const int32_t *__restrict__ rowptr,
+                                                    const int32_t *__restrict__ col, int64_t n_rows,
+                                                    float4 *__restrict__ out) {
+    const int l = threadIdx.x & 31;
+    for (int64_t n = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); n < n_rows; n += (int64_t)gridDim.x * 8) {
+        const int b = rowptr[n], e = rowptr[n + 1];
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        int j = b;
+        for (; j + 3 < e; j += 4) {
+            float4 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = src[(int64_t)(col ? col[j + q] : j + q) * 32 + l];
+            s = f4add(f4add(f4add(f4add(s, v[0]), v[1]), v[2]), v[3]);
+        }
+        for (; j < e; ++j) s = f4add(s, src[(int64_t)(col ? col[j] : j) * 32 + l]);
+        out[n * 32 + l] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pair_add(const float4 *__restrict__ c, const float4 *__restrict__ U,
+                                                  const int32_t *__restrict__ hi, const float4 *__restrict__ V,
+                                                  const int32_t *__restrict__ wi, const int32_t *__restrict__ n_dev,
+                                                  int64_t cap, float4 *__restrict__ out) {
+    int64_t n = *n_dev;
+    if (n < 0 || n > cap) n = cap;
+    const int l = threadIdx.x & 31;
+    for (int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); i < n; i += (int64_t)gridDim.x * 8)
+        out[i * 32 + l] = f4add(f4add(c[i * 32 + l], U[(int64_t)hi[i] * 32 + l]), V[(int64_t)wi[i] * 32 + l]);
+}
+
+}  // namespace lgcn
+
+using namespace lgcn;
+
+extern "C" {
+
+int lgcn_gn_bwd(const float *dy, const float *x, const float *post, const float *gamma, int64_t n_rows, float eps,
+                float *dx, float *dg_out, float *dgamma, float *dbeta, float *part, void *stream) {
+    if (n_rows < 0) return LGCN_EINVAL;
+    if (n_rows == 0) return LGCN_OK;
+    if (n_rows > 0x7fffffff) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(dy); LGCN_CHECK_PTR(dx);
+    LGCN_CHECK_ALIGN16(dy); LGCN_CHECK_ALIGN16(dx);
+    if (post) LGCN_CHECK_ALIGN16(post);
+    if (dg_out) LGCN_CHECK_ALIGN16(dg_out);
+    if (gamma) {
+        LGCN_CHECK_PTR(x); LGCN_CHECK_PTR(part);
+        LGCN_CHECK_ALIGN16(x); LGCN_CHECK_ALIGN16(gamma);
+    }
+    const int nb = (int)((n_rows + 31) / 32);
+    hipLaunchKernelGGL(k_gn_bwd, dim3(nb), dim3(256), 0, (hipStream_t)stream, dy, x, post, gamma, n_rows, eps, dx, dg_out, part);
+    if (gamma && (dgamma || dbeta))
+        hipLaunchKernelGGL(k_colsum_parts, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nb, dgamma, dbeta);
+    return launch_status();
+}
+
+int lgcn_gn_fwd(const float *x, const float *gamma, const float *beta, const float *res, int64_t n_rows, float eps,
+                int relu, float *out, void *stream) {
+    if (n_rows < 0) return LGCN_EINVAL;
+    if (n_rows == 0) return LGCN_OK;
+    if (n_rows > 0x7fffffff) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(x); LGCN_CHECK_PTR(out);
+    LGCN_CHECK_ALIGN16(x); LGCN_CHECK_ALIGN16(out);
+    if (gamma) { LGCN_CHECK_PTR(beta); LGCN_CHECK_ALIGN16(gamma); LGCN_CHECK_ALIGN16(beta); }
+    if (res) LGCN_CHECK_ALIGN16(res);
+    hipLaunchKernelGGL(k_gn_fwd, dim3((unsigned)((n_rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       res, n_rows, eps, relu, out);
+    return launch_status();
+}
+
+int lgcn_gather_sum(const float *src, const int32_t *rowptr, const int32_t *col, int64_t n_rows, float *out,
+                    void *stream) {
+    if (n_rows < 0) return LGCN_EINVAL;
+    if (n_rows == 0) return LGCN_OK;
+    LGCN_CHECK_PTR(src); LGCN_CHECK_PTR(rowptr); LGCN_CHECK_PTR(out);
+    LGCN_CHECK_ALIGN16(src); LGCN_CHECK_ALIGN16(out);
+    int64_t blocks = (n_rows + 7) / 8;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_gather_sum, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(src), rowptr, col, n_rows, reinterpret_cast<float4 *>(out));
+    return launch_status();
+}
+
+int lgcn_pair_add(const float *c, const float *U, const int32_t *hi, const float *V, const int32_t *wi,
+                  const int32_t *n_dev, int64_t cap, float *out, void *stream) {
+    if (cap < 0) return LGCN_EINVAL;
+    if (cap == 0) return LGCN_OK;
+    const void *ptrs[] = {c, U, hi, V, wi, n_dev, out};
+    for (const void *q : ptrs) LGCN_CHECK_PTR(q);
+    const void *al[] = {c, U, V, out};
+    for (const void *q : al) LGCN_CHECK_ALIGN16(q);
+    int64_t blocks = (cap + 7) / 8;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_pair_add, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(c), reinterpret_cast<const float4 *>(U), hi,
+                       reinterpret_cast<const float4 *>(V), wi, n_dev, cap, reinterpret_cast<float4 *>(out));
+    return launch_status();
+}
+
+int lgcn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev, int64_t cap, float *out, void *stream) {
+    if (cap < 0) return LGCN_EINVAL;
+    if (cap == 0) return LGCN_OK;
+    LGCN_CHECK_PTR(src); LGCN_CHECK_PTR(idx); LGCN_CHECK_PTR(n_dev); LGCN_CHECK_PTR(out);
+    LGCN_CHECK_ALIGN16(src); LGCN_CHECK_ALIGN16(out);
+    int64_t blocks = (cap + 7) / 8;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(src), idx, n_dev, cap, reinterpret_cast<float4 *>(out));
+    return launch_status();
+}
+
+}  // extern "C"

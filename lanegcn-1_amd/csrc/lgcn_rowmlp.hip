@@ -45,13 +45,13 @@ __device__ __forceinline__ void acc_to_lds(float *T, const f32x16 &acc, int lane
 
 // ------------------------------------------------------------ packing -----
 __global__ __launch_bounds__(256) void k_pack_weight(const float *__restrict__ W, int ld, int k_real, int k_pad,
-                                                     float *__restrict__ out) {
+                                                     float *__restrict__ out, int transpose) {
     const int nq = k_pad >> 3;
     const int total = 4 * nq * 64 * 4;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int j = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % nq, w = (i >> 8) / nq;
         const int row = 32 * w + (lane & 31), k = 8 * q + 4 * (lane >> 5) + j;
-        out[i] = k < k_real ? W[(int64_t)row * ld + k] : 0.f;
+        out[i] = k < k_real ? (transpose ? W[(int64_t)k * ld + row] : W[(int64_t)row * ld + k]) : 0.f;
     }
 }
 
@@ -207,6 +207,7 @@ __global__ __launch_bounds__(512) void k_agg_mlp(const lgcn_agg_mlp_t p, int n_t
         if (live && p.out_pre) row_store_global(p.out_pre + n * kC, tid, r);
         if (flags & LGCN_F_GN1) row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
         if (flags & LGCN_F_RELU1) row_relu(r);
+        if (live && p.out_mid) row_store_global(p.out_mid + n * kC, tid, r);
         row_store_lds(buf0, tid, r);
     }
     __syncthreads();
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(512) void k_agg_mlp(const lgcn_agg_mlp_t p, int n_t
     __syncthreads();
     if (tid < 256) {
         RowVals r = row_load(buf1, tid);
+        if (live && p.out_pre2) row_store_global(p.out_pre2 + n * kC, tid, r);
         if (flags & LGCN_F_GN2) row_gn(r, tid, p.gn2_g, p.gn2_b, p.eps);
         if (live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
         if (flags & LGCN_F_RELU2) row_relu(r);
@@ -339,6 +341,115 @@ __global__ __launch_bounds__(256) void k_att_pairs(const PairParams p) {
     }
 }
 
+
+// ------------------------------------------------------------- wgrad ------
+// dW[r] = dT^T (G_r src_r): block (chunk, r) walks the 32-row tiles chunk, chunk + n_chunks, ... that
+// relation r touches; waves 4-7 stage the gathered source rows and the dT rows of the next tile in LDS
+// while waves 0-3 contract the current one over its rows on v_mfma_f32_32x32x2_f32 (K-step = 2 rows;
+// with lanes along the channel axis both operands are plain row reads, no transpose).  Wave w owns the
+// 64 x 64 block (w >> 1, w & 1) of the 128 x 128 result; partials per chunk are summed by k_wgrad_reduce.
+__device__ __forceinline__ bool wgrad_tile_active(const lgcn_agg_mlp_t &p, int r, int64_t tile) {
+    const int mode = p.rel[r].mode;
+    if (mode == LGCN_REL_CSR) {
+        const int64_t n_sub = (p.n_rows + 15) >> 4;
+        bool on = false;
+        for (int h = 0; h < 2; ++h) {
+            const int64_t sub = tile * 2 + h;
+            if (sub < n_sub) {
+                const int64_t k0 = (sub * p.n_rel_csr + p.rel[r].ridx) * 16;
+                on = on || p.rowptr[k0 + 16] > p.rowptr[k0];
+            }
+        }
+        return on;
+    }
+    if (mode == LGCN_REL_RANGE) {
+        const int64_t r0 = tile * kTM32, r1 = r0 + kTM32 < p.n_rows ? r0 + kTM32 : p.n_rows;
+        return p.rowptr[r1] > p.rowptr[r0];
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(512) void k_wgrad(const lgcn_agg_mlp_t p, const float *__restrict__ dT,
+                                               float *__restrict__ part, int n_tiles, int n_chunks) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * kTileFloats];
+    auto bufA = [&](int b) { return smem + b * kTileFloats; };
+    auto bufD = [&](int b) { return smem + (2 + b) * kTileFloats; };
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = blockIdx.y, chunk = blockIdx.x;
+
+    auto next_active = [&](int64_t t) -> int64_t {
+        while (t < n_tiles && !wgrad_tile_active(p, r, t)) t += n_chunks;
+        return t;
+    };
+    auto fill = [&](int b, int64_t t) {   // waves 4-7
+        const int gt = tid - 256;
+        gather_rel(bufA(b), p, r, (int)t, gt);
+        const int hw = gt >> 5, l = gt & 31;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + hw;
+            const int64_t n = t * kTM32 + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < p.n_rows) v = reinterpret_cast<const float4 *>(dT)[n * 32 + l];
+            *reinterpret_cast<float4 *>(bufD(b) + row * kLDA + 4 * l) = v;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+
+    int64_t t = next_active(chunk);
+    if (wave >= 4 && t < n_tiles) fill(0, t);
+    __syncthreads();
+    int b = 0;
+    const int wj = wave >> 1, wk = wave & 1, i = lane & 31, kk = lane >> 5;
+    while (t < n_tiles) {
+        const int64_t tn = next_active(t + n_chunks);
+        if (wave < 4) {
+            const float *D = bufD(b) + kk * kLDA + 64 * wj + i;
+            const float *A = bufA(b) + kk * kLDA + 64 * wk + i;
+#pragma unroll 4
+            for (int s = 0; s < 16; ++s) {
+                const float a0 = D[2 * s * kLDA], a1 = D[2 * s * kLDA + 32];
+                const float b0 = A[2 * s * kLDA], b1 = A[2 * s * kLDA + 32];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        } else if (tn < n_tiles) {
+            fill(b ^ 1, tn);
+        }
+        __syncthreads();
+        t = tn;
+        b ^= 1;
+    }
+    if (wave < 4) {
+        float *o = part + ((int64_t)r * n_chunks + chunk) * (kC * kC);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 16; ++g)
+                    o[(64 * wj + 32 * jb + acc_row(g, lane)) * kC + 64 * wk + 32 * kb + i] = acc[jb][kb][g];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const float *__restrict__ part, int n_chunks, float *__restrict__ dW) {
+    const int r = blockIdx.y;
+    const int e = blockIdx.x * 256 + threadIdx.x;   // < 128*128
+    const float *p = part + (int64_t)r * n_chunks * (kC * kC) + e;
+    float s = 0.f;
+    for (int c = 0; c < n_chunks; ++c) s += p[(int64_t)c * (kC * kC)];
+    dW[(int64_t)r * (kC * kC) + e] = s;
+}
+
 }  // namespace lgcn
 
 using namespace lgcn;
@@ -360,11 +471,21 @@ int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad, int mma, voi
     LGCN_CHECK_ALIGN16(out);
     if (mma != LGCN_MMA_F32) {
         if (k_real != kC || k_pad != kC) return LGCN_ESHAPE;
-        return pack_weight_bf(W, ld, mma, out, (hipStream_t)stream);
+        return pack_weight_bf(W, ld, mma, 0, out, (hipStream_t)stream);
     }
     const int total = kC * k_pad;
     hipLaunchKernelGGL(k_pack_weight, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, W, ld, k_real, k_pad,
-                       reinterpret_cast<float *>(out));
+                       reinterpret_cast<float *>(out), 0);
+    return launch_status();
+}
+
+int lgcn_pack_weight_t(const float *W, int ld, int mma, void *out, void *stream) {
+    LGCN_CHECK_PTR(W); LGCN_CHECK_PTR(out);
+    if (!valid_mma(mma) || ld < kC) return LGCN_EINVAL;
+    LGCN_CHECK_ALIGN16(out);
+    if (mma != LGCN_MMA_F32) return pack_weight_bf(W, ld, mma, 1, out, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_pack_weight, dim3(kC * kC / 256), dim3(256), 0, (hipStream_t)stream, W, ld, kC, kC,
+                       reinterpret_cast<float *>(out), 1);
     return launch_status();
 }
 
@@ -442,6 +563,33 @@ int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs, const int32_t *
     int64_t tiles = (cap + kTM32 - 1) / kTM32;
     const unsigned grid = (unsigned)(tiles < 2048 ? tiles : 2048);
     hipLaunchKernelGGL(k_att_pairs, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status();
+}
+
+int lgcn_wgrad(const lgcn_agg_mlp_t *ph, const float *dT, float *dW, float *part, int n_chunks, void *stream) {
+    LGCN_CHECK_PTR(ph); LGCN_CHECK_PTR(dT); LGCN_CHECK_PTR(dW); LGCN_CHECK_PTR(part);
+    const lgcn_agg_mlp_t &p = *ph;
+    if (p.n_rows < 0 || p.n_rel < 1 || p.n_rel > LGCN_MAX_REL || n_chunks < 1 || n_chunks > 64) return LGCN_EINVAL;
+    if (p.n_rows > 0x7fffffff) return LGCN_ESHAPE;
+    LGCN_CHECK_ALIGN16(dT); LGCN_CHECK_ALIGN16(dW); LGCN_CHECK_ALIGN16(part);
+    bool need_rowptr = false, need_col = false;
+    for (int r = 0; r < p.n_rel; ++r) {
+        LGCN_CHECK_PTR(p.rel[r].src); LGCN_CHECK_ALIGN16(p.rel[r].src);
+        switch (p.rel[r].mode) {
+            case LGCN_REL_IDENT: break;
+            case LGCN_REL_CSR:
+                if (p.rel[r].ridx < 0 || p.rel[r].ridx >= p.n_rel_csr) return LGCN_EINVAL;
+                need_rowptr = need_col = true; break;
+            case LGCN_REL_RANGE: need_rowptr = true; break;
+            default: return LGCN_EINVAL;
+        }
+    }
+    if (need_rowptr) LGCN_CHECK_PTR(p.rowptr);
+    if (need_col) LGCN_CHECK_PTR(p.col);
+    hipStream_t st = (hipStream_t)stream;
+    const int n_tiles = (int)((p.n_rows + kTM32 - 1) / kTM32);
+    hipLaunchKernelGGL(k_wgrad, dim3(n_chunks, p.n_rel), dim3(512), 0, st, p, dT, part, n_tiles, n_chunks);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(kC * kC / 256, p.n_rel), dim3(256), 0, st, part, n_chunks, dW);
     return launch_status();
 }
 

@@ -230,15 +230,16 @@ __device__ __forceinline__ void row_split_store(uint16_t *planes, int plane_elem
 
 // ------------------------------------------------------------ packing -----
 template <int F>
-__global__ __launch_bounds__(256) void k_pack_weight_bf(const float *__restrict__ W, int ld, uint16_t *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_pack_weight_bf(const float *__restrict__ W, int ld, uint16_t *__restrict__ out,
+                                                        int transpose) {
     // one thread per (w, s, cb, lane): 8 consecutive k of one weight row -> 8 elements per plane
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4 * 4 * 2 * 64) return;
     const int lane = i & 63, cb = (i >> 6) & 1, s = (i >> 7) & 3, w = i >> 9;
-    const float *src = W + (int64_t)(32 * w + 16 * cb + (lane & 15)) * ld + 32 * s + 8 * (lane >> 4);
+    const int orow = 32 * w + 16 * cb + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = src[j];
+    for (int j = 0; j < 8; ++j) v[j] = transpose ? W[(int64_t)(k0 + j) * ld + orow] : W[(int64_t)orow * ld + k0 + j];
 #pragma unroll
     for (int p = 0; p < Fmt<F>::NP; ++p) {
         uint32_t q[4];
@@ -521,6 +522,7 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
                 if (flags & LGCN_F_GN1) row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
                 if (!two && live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
                 if (flags & LGCN_F_RELU1) row_relu(r);
+                if (two && live && p.out_mid) row_store_global(p.out_mid + n * kC, tid, r);
                 if (two) row_split_store<F>(Yp, TL::PLANE, row, tid, r);
                 else if (live) row_store_global(p.out + n * kC, tid, r);
             }
@@ -546,6 +548,7 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
                 const int64_t n = row0 + row;
                 const bool live = n < p.n_rows;
                 RowVals r = row_load(T + c0 * kLDA, tid);
+                if (live && p.out_pre2) row_store_global(p.out_pre2 + n * kC, tid, r);
                 if (flags & LGCN_F_GN2) row_gn(r, tid, p.gn2_g, p.gn2_b, p.eps);
                 if (live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
                 if (flags & LGCN_F_RELU2) row_relu(r);
@@ -804,12 +807,12 @@ int att_pairs_bf(const PairParams &p, int mma, hipStream_t st) {
     return launch_status();
 }
 
-int pack_weight_bf(const float *W, int ld, int mma, void *out, hipStream_t st) {
+int pack_weight_bf(const float *W, int ld, int mma, int transpose, void *out, hipStream_t st) {
     uint16_t *o = reinterpret_cast<uint16_t *>(out);
     switch (fmt_of(mma)) {
-        case 0: hipLaunchKernelGGL((k_pack_weight_bf<0>), dim3(8), dim3(256), 0, st, W, ld, o); break;
-        case 1: hipLaunchKernelGGL((k_pack_weight_bf<1>), dim3(8), dim3(256), 0, st, W, ld, o); break;
-        default: hipLaunchKernelGGL((k_pack_weight_bf<2>), dim3(8), dim3(256), 0, st, W, ld, o); break;
+        case 0: hipLaunchKernelGGL((k_pack_weight_bf<0>), dim3(8), dim3(256), 0, st, W, ld, o, transpose); break;
+        case 1: hipLaunchKernelGGL((k_pack_weight_bf<1>), dim3(8), dim3(256), 0, st, W, ld, o, transpose); break;
+        default: hipLaunchKernelGGL((k_pack_weight_bf<2>), dim3(8), dim3(256), 0, st, W, ld, o, transpose); break;
     }
     return launch_status();
 }

@@ -106,6 +106,6 @@ struct PairParams {
 int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st);
 int mapnet_input_bf(const InputParams &p, int mma, hipStream_t st);
 int att_pairs_bf(const PairParams &p, int mma, hipStream_t st);
-int pack_weight_bf(const float *W, int ld, int mma, void *out, hipStream_t st);
+int pack_weight_bf(const float *W, int ld, int mma, int transpose, void *out, hipStream_t st);
 
 }  // namespace lgcn

@@ -17,9 +17,10 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import _lib as L
+from . import autograd as A
 from . import ops
 from .data import collate_fn
-from .layers import Conv1d, Linear, LinearRes, Res1d
+from .layers import Conv1d, Linear, LinearRes, Res1d, group_norm1
 from .utils import Optimizer, StepLR, gpu, to_long
 
 file_path = os.path.abspath(__file__)
@@ -53,12 +54,13 @@ def _gn(m: nn.GroupNorm):
     return (m.weight, m.bias)
 
 
-def _hot_guard(*tensors):
-    """The hot path is HIP-only and forward-only: refuse CPU tensors and autograd loudly."""
+def _hot_guard(*tensors) -> bool:
+    """The hot path is HIP-only: refuse CPU tensors loudly.  Returns True when autograd must record the
+    call (then the differentiable composition of autograd.py runs instead of the fused inference kernels)."""
     for t in tensors:
         if isinstance(t, Tensor) and not t.is_cuda:
             raise L.LgcnError("LaneGCN hot-path modules need CUDA tensors (HIP kernels, no CPU fallback)")
-    ops._no_grad_guard(*[t for t in tensors if isinstance(t, Tensor)])
+    return ops.wants_grad(*[t for t in tensors if isinstance(t, Tensor)])
 
 
 # ------------------------------------------------------------------ gathers
@@ -162,6 +164,47 @@ def lane_plan(graph: Dict) -> ops.LanePlan:
     return plan
 
 
+def _coo_lists(graph: Dict):
+    us, vs = [], []
+    for i in range(len(graph["pre"])):
+        for k1 in ("pre", "suc"):
+            us.append(graph[k1][i]["u"])
+            vs.append(graph[k1][i]["v"])
+    for k1 in ("left", "right"):
+        us.append(graph[k1]["u"])
+        vs.append(graph[k1]["v"])
+    return us, vs
+
+
+def lane_plan_t(graph: Dict) -> ops.LanePlan:
+    """The same relations keyed by SOURCE (u and v swapped): the backward of a gather-by-destination is a
+    gather-by-source of the output gradients.  Built on first use in training, cached on the graph dict."""
+    plan = graph.get("_plan_t")
+    if plan is None:
+        us, vs = _coo_lists(graph)
+        plan = ops.csr_build(vs, us, int(graph["feats"].shape[0]))
+        graph["_plan_t"] = plan
+    return plan
+
+
+def lane_conv_train(fuse: nn.ModuleDict, feat: Tensor, plan: ops.LanePlan, plan_t: ops.LanePlan,
+                    num_scales: int) -> Tensor:
+    """lane_conv with autograd (LaneConvFn: fused forward launch, composed HIP backward)."""
+    keys = rel_keys(num_scales)
+    for i in range(len(fuse["ctr"])):
+        rels, weights = [A.Rel(0, 0, L.REL_IDENT)], [fuse["ctr"][i].weight]
+        for r, key in enumerate(keys):
+            if plan.n_edges[r] > 0:
+                rels.append(A.Rel(0, len(weights), L.REL_CSR, r))
+                weights.append(fuse[key][i].weight)
+        spec = A.BlockSpec(n_rows=feat.shape[0], rels=rels, gn=True, relu=True, has_res=True, eps=fuse["norm"][i].eps,
+                           plan=plan, plan_t=plan_t)
+        c2 = fuse["ctr2"][i]
+        feat = A.LaneConvFn.apply(spec, feat, fuse["norm"][i].weight, fuse["norm"][i].bias, c2.linear.weight,
+                                  c2.norm.weight, c2.norm.bias, *weights)
+    return feat
+
+
 def _fuse_modules(n_map: int, num_scales: int, ng: int = 1) -> nn.ModuleDict:
     """The reference's ``fuse`` ModuleDict (lanegcn.py:288-308): 4 layers of ctr/norm/ctr2/left/right/
     pre{i}/suc{i}; key order and module types fix the state_dict names."""
@@ -222,8 +265,14 @@ class MapNet(nn.Module):
             # the reference's early-return branch reads a key that graph_gather never sets
             # (lanegcn.py:312-322) and therefore raises KeyError; kept for error parity
             raise KeyError("node_idcs")
-        _hot_guard(graph["feats"], *self.parameters())
-        feat = self.stem(torch.cat(graph["ctrs"], 0), graph["feats"])
+        ctrs = torch.cat(graph["ctrs"], 0)
+        if _hot_guard(graph["feats"], *self.parameters()):
+            a, s = self.input, self.seg      # the two nn.Linear(2,128) are [N,2]-shaped: stock ops
+            fa = A.linear_gn(F.relu(a[0](ctrs)), a[2].linear.weight, gn=a[2].norm)
+            fs = A.linear_gn(F.relu(s[0](graph["feats"])), s[2].linear.weight, gn=s[2].norm)
+            feat = lane_conv_train(self.fuse, F.relu(fa + fs), lane_plan(graph), lane_plan_t(graph), len(graph["pre"]))
+            return feat, graph["idcs"], graph["ctrs"]
+        feat = self.stem(ctrs, graph["feats"])
         feat = lane_conv(self.fuse, feat, lane_plan(graph), len(graph["pre"]))
         return feat, graph["idcs"], graph["ctrs"]
 
@@ -238,7 +287,8 @@ class M2M(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, feat: Tensor, graph: Dict) -> Tensor:
-        _hot_guard(feat, *self.parameters())
+        if _hot_guard(feat, *self.parameters()):
+            return lane_conv_train(self.fuse, feat, lane_plan(graph), lane_plan_t(graph), len(graph["pre"]))
         return lane_conv(self.fuse, feat, lane_plan(graph), len(graph["pre"]))
 
 
@@ -281,18 +331,40 @@ class Att(nn.Module):
     def forward(self, agts: Tensor, agt_idcs: List[Tensor], agt_ctrs: List[Tensor], ctx: Tensor,
                 ctx_idcs: List[Tensor], ctx_ctrs: List[Tensor], dist_th: float,
                 pairs: Optional[ops.PairSet] = None) -> Tensor:
-        _hot_guard(agts, ctx, *self.parameters())
+        train = _hot_guard(agts, ctx, *self.parameters())
         T = agts.shape[0]
         lin = self.linear
         if len(ctx) == 0:   # lanegcn.py:664-670: no GroupNorm before the ReLU
+            if train:
+                a = A.linear_gn(agts, self.agt.weight, relu=True)
+                return A.linear_gn(a, lin.linear.weight, gn=lin.norm, relu=True, res=agts)
             return ops.agg_mlp(T, [ops.RelSpec(agts, ops.packed(self.agt.weight))],
                                L.F_RELU1 | L.F_GEMM2 | L.F_GN2 | L.F_RES | L.F_RELU2,
                                wp2=ops.packed(lin.linear.weight), gn2=_gn(lin.norm), res=agts, eps=lin.norm.eps)
         ps = pairs if pairs is not None else build_pairs(agt_idcs, agt_ctrs, ctx_idcs, ctx_ctrs, dist_th,
                                                          self.legacy_offsets)
-        if self.strict and ps.count() == 0:
+        if (self.strict or train) and ps.count() == 0:
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
-        return self.run(agts, ctx, ps)
+        return self.run_train(agts, ctx, ps) if train else self.run(agts, ctx, ps)
+
+    def run_train(self, agts: Tensor, ctx: Tensor, ps: ops.PairSet) -> Tensor:
+        """Differentiable composition of the same arithmetic as run() (lanegcn.py:691-709): per-pair tensors are
+        sized by the exact pair count (one host read per pair set, already paid by the emptiness check)."""
+        P, T = ps.count(), agts.shape[0]
+        lin, c0 = self.linear, self.ctx[0]
+        hi, wi = ps.hi[:P].long(), ps.wi[:P].long()
+        delta = ps.agt_ctrs[hi] - ps.ctx_ctrs[wi]                                   # [P,2]; centres carry no gradient
+        h1 = F.relu(self.dist[0](delta))                                           # nn.Linear(2,128): stock op
+        e = A.linear_gn(h1, self.dist[2].linear.weight, gn=self.dist[2].norm, relu=True)
+        q = A.linear_gn(agts, self.query.linear.weight, gn=self.query.norm, relu=True)
+        U = A.linear_gn(q, c0.linear.weight, col0=128)
+        V = A.linear_gn(ctx, c0.linear.weight, col0=256)
+        c = A.PairAddFn.apply(A.linear_gn(e, c0.linear.weight, col0=0), U, V, ps)
+        m = A.gn_act(c, gn=c0.norm, relu=True)
+        spec_kw = dict(rowptr=ps.rowptr, seg_ids=ps.hi, n_seg_rows=ps.n_pairs, tag="att_post")
+        y = A.row_block([agts, m], [self.agt.weight, self.ctx[1].weight],
+                        [A.Rel(0, 0, L.REL_IDENT), A.Rel(1, 1, L.REL_RANGE)], T, gn=self.norm, relu=True, **spec_kw)
+        return A.linear_gn(y, lin.linear.weight, gn=lin.norm, relu=True, res=agts)
 
     def run(self, agts: Tensor, ctx: Tensor, ps: ops.PairSet) -> Tensor:
         """The pair MLP + segment reduce + node epilogue for a given pair set (lanegcn.py:691-709)."""
@@ -335,8 +407,12 @@ class A2M(nn.Module):
 
     def forward(self, feat: Tensor, graph: Dict, actors: Tensor, actor_idcs: List[Tensor],
                 actor_ctrs: List[Tensor]) -> Tensor:
-        _hot_guard(feat, actors, *self.parameters())
-        feat = self.fuse_meta(feat, graph["turn"], graph["control"], graph["intersect"])
+        if _hot_guard(feat, actors, *self.parameters()):
+            w = self.meta.linear.weight       # 132 = 128 (HIP row block) + 4 meta columns ([N,4]: stock op)
+            meta4 = torch.cat((graph["turn"], graph["control"].unsqueeze(1), graph["intersect"].unsqueeze(1)), 1)
+            feat = A.gn_act(A.linear_gn(feat, w, col0=0) + F.linear(meta4, w[:, 128:132]), gn=self.meta.norm, relu=True)
+        else:
+            feat = self.fuse_meta(feat, graph["turn"], graph["control"], graph["intersect"])
         th = self.config["actor2map_dist"]
         ps = None
         if len(actors) > 0:
@@ -425,9 +501,8 @@ class AttDest(nn.Module):
     def forward(self, agts: Tensor, agt_ctrs: Tensor, dest_ctrs: Tensor) -> Tensor:
         n_agt, num_mods = agts.size(1), dest_ctrs.size(1)
         d = (agt_ctrs.unsqueeze(1) - dest_ctrs).reshape(-1, 2)
-        h = self.dist[1](self.dist[0](d))
-        d = F.relu(F.group_norm(F.linear(h, self.dist[2].linear.weight), 1, self.dist[2].norm.weight,
-                                self.dist[2].norm.bias, self.dist[2].norm.eps))
+        h = F.relu(self.dist[0](d))
+        d = group_norm1(F.linear(h, self.dist[2].linear.weight), self.dist[2].norm, relu=True)
         a = agts.unsqueeze(1).expand(-1, num_mods, -1).reshape(-1, n_agt)
         return self.agt(torch.cat((d, a), 1))
 

@@ -24,6 +24,28 @@ def _norm(norm, ng, n_out, dims):
     raise SystemExit("SyncBN has not been added!")
 
 
+def group_norm1(x, norm, relu=False):
+    """Apply `norm` so that its backward is correct on this stack.
+
+    Stock PyTorch-ROCm 2.10.0+rocm7.0 returns wrong dgamma / dbeta from GroupNorm's backward on the GPU once
+    the batch dimension exceeds ~128 (2-D and 3-D inputs alike; forward and dx are right) -- measured with
+    tools/check_aten_gn.py.  When gradients are needed on a CUDA tensor, GroupNorm(1 group) therefore runs on
+    the HIP row kernels ([rows,128] inputs) or on an explicit mean/var formula made of basic ops."""
+    if (not isinstance(norm, nn.GroupNorm) or norm.num_groups != 1 or not x.is_cuda
+            or not ops.wants_grad(x, norm.weight, norm.bias)):
+        out = norm(x)
+        return F.relu(out) if relu else out
+    if x.dim() == 2 and x.shape[1] == ops.C_FEAT:
+        from . import autograd as A
+        return A.gn_act(x.contiguous(), gn=norm, relu=relu)     # the ReLU is part of the Function (no in-place edit
+    dims = tuple(range(1, x.dim()))                             # of its saved output afterwards)
+    mean = x.mean(dims, keepdim=True)
+    var = x.var(dims, unbiased=False, keepdim=True)
+    shape = [1, -1] + [1] * (x.dim() - 2)
+    out = (x - mean) * torch.rsqrt(var + norm.eps) * norm.weight.view(shape) + norm.bias.view(shape)
+    return F.relu(out) if relu else out
+
+
 class Linear(nn.Module):
     """no-bias Linear -> GroupNorm -> optional ReLU (reference layers.py:65-87)."""
 
@@ -42,13 +64,14 @@ class Linear(nn.Module):
     def forward(self, x):
         if self._hot_shaped(x):
             # the graph hot path's shape: HIP only (CUDA tensors, no CPU fallback)
-            ops._no_grad_guard(x, *self.parameters())
+            if ops.wants_grad(x, *self.parameters()):
+                from . import autograd as A
+                return A.linear_gn(x, self.linear.weight, gn=self.norm, relu=self.act)
             flags = L.F_GN1 | (L.F_RELU1 if self.act else 0)
             return ops.agg_mlp(x.shape[0], [ops.RelSpec(x, ops.packed(self.linear.weight))], flags,
                                gn1=(self.norm.weight, self.norm.bias), eps=self.norm.eps)
         # other shapes (AttDest 256->128 in PredNet) are outside the hot path: stock ATen ops
-        out = self.norm(self.linear(x))
-        return self.relu(out) if self.act else out
+        return group_norm1(self.linear(x), self.norm, relu=self.act)
 
 
 class Conv1d(nn.Module):
@@ -63,8 +86,7 @@ class Conv1d(nn.Module):
         self.act = act
 
     def forward(self, x):
-        out = self.norm(self.conv(x))
-        return self.relu(out) if self.act else out
+        return group_norm1(self.conv(x), self.norm, relu=self.act)
 
 
 class Res1d(nn.Module):
@@ -86,10 +108,12 @@ class Res1d(nn.Module):
         self.act = act
 
     def forward(self, x):
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        out = out + (x if self.downsample is None else self.downsample(x))
-        return self.relu(out) if self.act else out
+        out = group_norm1(self.conv1(x), self.bn1, relu=True)
+        out = group_norm1(self.conv2(out), self.bn2)
+        if self.downsample is not None:
+            x = group_norm1(self.downsample[0](x), self.downsample[1])
+        out = out + x
+        return F.relu(out) if self.act else out
 
 
 class LinearRes(nn.Module):
@@ -108,10 +132,12 @@ class LinearRes(nn.Module):
             self.transform = None
 
     def forward(self, x):
-        out = self.relu(self.norm1(self.linear1(x)))
-        out = self.norm2(self.linear2(out))
-        out = out + (x if self.transform is None else self.transform(x))
-        return self.relu(out)
+        out = group_norm1(self.linear1(x), self.norm1, relu=True)
+        out = group_norm1(self.linear2(out), self.norm2)
+        if self.transform is not None:
+            x = group_norm1(self.transform[0](x), self.transform[1])
+        out = out + x
+        return F.relu(out)
 
 
 class Null(nn.Module):

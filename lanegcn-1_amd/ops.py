@@ -34,6 +34,23 @@ def get_mma() -> str:
     return {v: k for k, v in L.MMA_NAMES.items()}[_mma]
 
 
+class backward_mma:
+    """Matrix-core mode for the row-GEMMs of a backward pass: gradients routinely sit below fp16's normal
+    range (6e-5), where the 2-way fp16 split loses its second plane, so f16x2 forwards run their backward
+    GEMMs on the range-safe 3-way bf16 split (same fp32-grade accuracy, fp32 exponent range)."""
+
+    def __enter__(self):
+        global _mma
+        self.prev = _mma
+        if _mma == L.MMA_F16X2:
+            _mma = L.MMA_BF16X3
+        return self
+
+    def __exit__(self, *a):
+        global _mma
+        _mma = self.prev
+
+
 def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -50,12 +67,9 @@ def _ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
-def _no_grad_guard(*tensors):
-    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise L.LgcnError(
-            "the HIP hot path is forward-only in this release: call it under torch.no_grad() "
-            "(silently dropping gradients would be wrong)"
-        )
+def wants_grad(*tensors) -> bool:
+    """True when autograd must record this call (then the differentiable path of autograd.py runs)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors)
 
 
 # ------------------------------------------------------------------ integer path
@@ -127,6 +141,19 @@ class PairSet:
             if self._p_host < 0:
                 raise L.LgcnError("pair capacity %d exceeded (P = %d)" % (self.cap, -self._p_host))
         return self._p_host
+
+    def csr_by_wi(self, n_ctx: int):
+        """Plain CSR of the pairs by context row (rowptr [S+1], col = pair ids, int32): the transpose of the
+        gather V[wi] needed by the backward.  Index plumbing on ATen integer ops, cached."""
+        if getattr(self, "_wcsr", None) is None:
+            P = self.count()
+            wi = self.wi[:P].long()
+            order = torch.argsort(wi, stable=True)
+            counts = torch.bincount(wi, minlength=n_ctx)
+            rowptr = torch.zeros(n_ctx + 1, dtype=torch.int32, device=wi.device)
+            rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            self._wcsr = (rowptr, order.to(torch.int32).contiguous())
+        return self._wcsr
 
     def hi_wi_long(self):
         """(hi, wi) as the reference's LongTensors [P] (test/debug accessor; syncs once)."""
@@ -207,6 +234,24 @@ def packed(weight: torch.Tensor, col0: int = 0, k: Optional[int] = None) -> torc
     return _cached(weight, ("pack", col0, k, mma), make)
 
 
+def packed_t(weight: torch.Tensor, col0: int = 0) -> torch.Tensor:
+    """MFMA image of the TRANSPOSE of the square block weight[:, col0:col0+128]: the backward of
+    y = x W^T is dx = dy W, a Linear whose weight is W^T.  Cached like packed()."""
+    lib = L.load()
+    if weight.dim() != 2 or weight.shape[0] != C_FEAT or weight.shape[1] < col0 + C_FEAT:
+        raise L.LgcnError("packed_t(): need a [128, >= col0+128] weight")
+    mma = _mma
+
+    def make():
+        w = _dev(weight.detach(), torch.float32, "weight")
+        out = torch.empty(lib.lgcn_packed_bytes(C_FEAT, mma) // 4, dtype=torch.float32, device=w.device)
+        L.check(lib.lgcn_pack_weight_t(C.c_void_p(w[:, col0:].data_ptr()), w.stride(0), mma, _ptr(out), _stream()),
+                "lgcn_pack_weight_t")
+        return out
+
+    return _cached(weight, ("packT", col0, mma), make)
+
+
 def cols4(weight: torch.Tensor, col0: int) -> torch.Tensor:
     """Contiguous [128, 4] copy of weight[:, col0:col0+4] (the 4 meta columns of A2M.meta), cached."""
     return _cached(weight, ("c4", col0), lambda: _dev(weight.detach(), torch.float32, "weight")[:, col0:col0 + 4].contiguous())
@@ -260,13 +305,14 @@ class _Timed:
 @dataclass
 class RelSpec:
     src: torch.Tensor
-    wp: torch.Tensor
+    wp: Optional[torch.Tensor]      # packed weight (None for lgcn_wgrad)
     mode: int = L.REL_IDENT
     ridx: int = 0
 
 
 def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, col=None, n_rel_csr=0,
-            gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, eps=EPS, tag=None, tile_rb=0):
+            gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, out_mid=None, out_pre2=None, eps=EPS, tag=None,
+            tile_rb=0):
     """Fused aggregate -> GEMM -> GN -> ReLU -> GEMM -> GN -> +res -> ReLU row block (lgcn_agg_mlp)."""
     lib = L.load()
     if not rels or len(rels) > L.MAX_REL:
@@ -280,6 +326,7 @@ def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, co
         s = _dev(r.src, torch.float32, "rel.src")
         keep.append(s)
         p.rel[i].src, p.rel[i].wp, p.rel[i].mode, p.rel[i].ridx = s.data_ptr(), r.wp.data_ptr(), r.mode, r.ridx
+        keep.append(r.wp)
     p.rowptr = 0 if rowptr is None else rowptr.data_ptr()
     p.col = 0 if col is None else col.data_ptr()
     if w4 is not None:
@@ -300,6 +347,8 @@ def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, co
         out = torch.empty((n_rows, C_FEAT), dtype=torch.float32, device=dev)
     p.out = out.data_ptr()
     p.out_pre = 0 if out_pre is None else out_pre.data_ptr()
+    p.out_mid = 0 if out_mid is None else out_mid.data_ptr()
+    p.out_pre2 = 0 if out_pre2 is None else out_pre2.data_ptr()
     with _Timed(tag):
         L.check(lib.lgcn_agg_mlp(C.byref(p), _stream()), "lgcn_agg_mlp")
     return out
@@ -327,3 +376,83 @@ def att_pairs(ps: PairSet, wd0, bd0, wpd2, gn_d, wpc0e, U, V, gn_c, m=None, eps=
                                 _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _mma, _ptr(m), _stream())
     L.check(rc, "lgcn_att_pairs")
     return m
+
+
+# ------------------------------------------------------------------ backward building blocks
+def gn_fwd(x, gn=None, res=None, relu=False, eps=EPS):
+    """out = [ReLU](GroupNorm(1,128)(x) [+ res]) as a stand-alone row kernel."""
+    lib = L.load()
+    x = _dev(x, torch.float32, "x")
+    out = torch.empty_like(x)
+    g, b = (gn[0], gn[1]) if gn is not None else (None, None)
+    res = None if res is None else _dev(res, torch.float32, "res")
+    L.check(lib.lgcn_gn_fwd(_ptr(x), _ptr(g), _ptr(b), _ptr(res), x.shape[0], eps, int(bool(relu)), _ptr(out), _stream()),
+            "lgcn_gn_fwd")
+    return out
+
+
+def gn_bwd(dy, x, post, gamma, eps=EPS, want_g=False):
+    """Backward of out = [ReLU](GN(x) [+res]): returns (dx, g, dgamma, dbeta); g = dy masked by post > 0
+    (the gradient into `res`), None unless want_g.  gamma None: mask only."""
+    lib = L.load()
+    dy = _dev(dy, torch.float32, "dy")
+    n = dy.shape[0]
+    dx = torch.empty_like(dy)
+    g = torch.empty_like(dy) if want_g else None
+    if gamma is None:
+        L.check(lib.lgcn_gn_bwd(_ptr(dy), None, _ptr(post), None, n, eps, _ptr(dx), _ptr(g), None, None, None, _stream()),
+                "lgcn_gn_bwd")
+        return dx, g, None, None
+    x = _dev(x, torch.float32, "x")
+    dgamma = torch.empty(C_FEAT, dtype=torch.float32, device=dy.device)
+    dbeta = torch.empty_like(dgamma)
+    part = torch.empty(2 * ((n + 31) // 32) * C_FEAT, dtype=torch.float32, device=dy.device)
+    L.check(lib.lgcn_gn_bwd(_ptr(dy), _ptr(x), _ptr(post), _ptr(gamma), n, eps, _ptr(dx), _ptr(g), _ptr(dgamma),
+                            _ptr(dbeta), _ptr(part), _stream()), "lgcn_gn_bwd")
+    return dx, g, dgamma, dbeta
+
+
+def wgrad(n_rows: int, rels: Sequence[RelSpec], dT: torch.Tensor, *, rowptr=None, col=None, n_rel_csr=0,
+          n_chunks: int = 16) -> torch.Tensor:
+    """dW[r] = dT^T (G_r src_r) for every relation: [n_rel,128,128] fp32."""
+    lib = L.load()
+    dT = _dev(dT, torch.float32, "dT")
+    p = L.AggMlp()
+    p.n_rows, p.n_rel, p.n_rel_csr = n_rows, len(rels), n_rel_csr
+    keep = []
+    for i, r in enumerate(rels):
+        s = _dev(r.src, torch.float32, "rel.src")
+        keep.append(s)
+        p.rel[i].src, p.rel[i].mode, p.rel[i].ridx = s.data_ptr(), r.mode, r.ridx
+    p.rowptr = 0 if rowptr is None else rowptr.data_ptr()
+    p.col = 0 if col is None else col.data_ptr()
+    n_chunks = max(1, min(n_chunks, (n_rows + 31) // 32, 64))
+    dW = torch.empty((len(rels), C_FEAT, C_FEAT), dtype=torch.float32, device=dT.device)
+    part = torch.empty(len(rels) * n_chunks * C_FEAT * C_FEAT, dtype=torch.float32, device=dT.device)
+    L.check(lib.lgcn_wgrad(C.byref(p), _ptr(dT), _ptr(dW), _ptr(part), n_chunks, _stream()), "lgcn_wgrad")
+    return dW
+
+
+def gather_rows(src, idx, n_dev, cap):
+    lib = L.load()
+    src = _dev(src, torch.float32, "src")
+    out = torch.empty((max(cap, 1), C_FEAT), dtype=torch.float32, device=src.device)
+    L.check(lib.lgcn_gather_rows(_ptr(src), _ptr(idx), _ptr(n_dev), cap, _ptr(out), _stream()), "lgcn_gather_rows")
+    return out[:cap]
+
+
+def gather_sum(src, rowptr, col, n_rows):
+    lib = L.load()
+    src = _dev(src, torch.float32, "src")
+    out = torch.empty((n_rows, C_FEAT), dtype=torch.float32, device=src.device)
+    L.check(lib.lgcn_gather_sum(_ptr(src), _ptr(rowptr), _ptr(col), n_rows, _ptr(out), _stream()), "lgcn_gather_sum")
+    return out
+
+
+def pair_add(c, U, hi, V, wi, n_dev, cap):
+    lib = L.load()
+    c = _dev(c, torch.float32, "c")
+    out = torch.empty_like(c)
+    L.check(lib.lgcn_pair_add(_ptr(c), _ptr(U), _ptr(hi), _ptr(V), _ptr(wi), _ptr(n_dev), cap, _ptr(out), _stream()),
+            "lgcn_pair_add")
+    return out

@@ -130,6 +130,54 @@ def main():
     np.savez_compressed(os.path.join(HERE, "hotpath_b4.npz"), **out)
     print("wrote hotpath_b4.npz:", {k: v.shape for k, v in out.items() if not k.startswith("scenes/")})
 
+    # ---- one training step of the reference: loss (lanegcn.py:740-821), backward, Adam step through the
+    # reference's Optimizer (utils.py:98-162) at epoch 0 (lr 1e-3)
+    tr = {"seed": np.int64(SEED)}
+    net.zero_grad()
+    batch = refdata.collate_fn(copy.deepcopy(scenes))
+    loss_fn = ref.Loss(ref.config)
+    outp = net(batch)
+    loss_out = loss_fn(outp, batch)
+    loss_out["loss"].backward()
+    for k in ("cls_loss", "reg_loss", "loss"):
+        tr["loss/" + k] = np.float64(loss_out[k].item())
+    tr["loss/num_cls"] = np.int64(loss_out["num_cls"])
+    tr["loss/num_reg"] = np.int64(loss_out["num_reg"])
+    names = [k for k, _ in net.named_parameters()]
+    tr["grad_norms"] = np.array([float(p.grad.norm()) if p.grad is not None else -1.0 for _, p in net.named_parameters()])
+    picked = [n for n in names if n in SELECTED]
+    assert len(picked) == len(SELECTED), set(SELECTED) - set(picked)
+    params = dict(net.named_parameters())
+    for n in picked:
+        tr["grad/" + n] = params[n].grad.numpy().copy()
+    opt = ref.Optimizer(net.parameters(), ref.config)
+    lr = opt.step(0.0)
+    tr["lr"] = np.float64(lr)
+    for n in picked:     # post-step values of the small tensors + one matrix (the step itself is stock Adam)
+        if params[n].numel() <= 512 or n == "map_net.fuse.ctr.0.weight":
+            tr["after/" + n] = params[n].detach().numpy().copy()
+    with open(os.path.join(HERE, "param_names.json"), "w") as f:
+        json.dump(names, f)
+    np.savez_compressed(os.path.join(HERE, "train_b4.npz"), **tr)
+    print("wrote train_b4.npz: loss %.6f cls %.6f reg %.6f num_cls %d num_reg %d" % (
+        tr["loss/loss"], tr["loss/cls_loss"], tr["loss/reg_loss"], tr["loss/num_cls"], tr["loss/num_reg"]))
+
+
+SELECTED = [
+    "actor_net.groups.0.0.conv1.weight", "actor_net.output.conv2.weight",
+    "map_net.input.0.weight", "map_net.input.0.bias", "map_net.input.2.linear.weight", "map_net.input.2.norm.weight",
+    "map_net.seg.2.norm.bias", "map_net.fuse.ctr.0.weight", "map_net.fuse.pre3.2.weight", "map_net.fuse.left.1.weight",
+    "map_net.fuse.suc0.3.weight", "map_net.fuse.norm.3.weight", "map_net.fuse.norm.3.bias",
+    "map_net.fuse.ctr2.0.linear.weight", "map_net.fuse.ctr2.2.norm.weight",
+    "a2m.meta.linear.weight", "a2m.meta.norm.bias", "a2m.att.0.dist.0.weight", "a2m.att.0.dist.0.bias",
+    "a2m.att.0.dist.2.linear.weight", "a2m.att.0.dist.2.norm.weight", "a2m.att.0.query.linear.weight",
+    "a2m.att.0.ctx.0.linear.weight", "a2m.att.0.ctx.0.norm.bias", "a2m.att.0.ctx.1.weight", "a2m.att.0.agt.weight",
+    "a2m.att.0.norm.weight", "a2m.att.0.linear.linear.weight", "a2m.att.1.linear.norm.bias",
+    "m2m.fuse.suc5.3.weight", "m2m.fuse.ctr.1.weight", "m2m.fuse.right.0.weight",
+    "m2a.att.1.ctx.0.linear.weight", "m2a.att.0.query.norm.weight", "a2a.att.0.agt.weight", "a2a.att.1.query.norm.weight",
+    "a2a.att.1.ctx.1.weight", "pred_net.cls.1.weight", "pred_net.att_dest.dist.2.linear.weight",
+]
+
 
 def out_t(a):
     import torch

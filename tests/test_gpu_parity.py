@@ -267,9 +267,6 @@ def test_error_behaviour_matches_reference(gcase, hip):
     with pytest.raises(LgcnError):
         mods["m2m"].cpu()(torch.zeros(4, 128), {})
     mods["m2m"].cuda()
-    # autograd is refused rather than silently dropped
-    with pytest.raises(LgcnError):
-        mods["m2m"](torch.zeros(4, 128, device="cuda", requires_grad=True), {})
 
 
 def test_s2_batch_vs_oracle_and_properties(hip, ref_state_names):

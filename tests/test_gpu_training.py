@@ -1,0 +1,230 @@
+"""GPU: one training step through the drop-in Net (HIP forward + HIP backward of the hot path) against the
+reference's own loss, gradients and Adam update (tests/golden/train_b4.npz, captured by make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden_io import load_scenes
+from oracle import lanegcn_oracle as O
+
+pytestmark = pytest.mark.gpu
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def train_golden():
+    with np.load(os.path.join(GOLDEN_DIR, "train_b4.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+@pytest.fixture(params=["f32", "f16x2"])
+def mma(request):
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import ops
+    prev = ops.get_mma()
+    ops.set_mma(request.param)
+    yield request.param
+    ops.set_mma(prev)
+
+
+def rel_err(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def test_training_step_matches_reference(golden, train_golden, ref_state_names, mma):
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import data as gen
+    from lanegcn_amd import lanegcn as M
+    scenes = load_scenes(golden)
+    net = M.Net(M.config)
+    net.load_state_dict(O.seeded_state(ref_state_names, int(train_golden["seed"])), strict=True)
+    net = net.cuda().train()
+    loss_fn = M.Loss(M.config).cuda()
+    batch = gen.collate_fn(scenes)
+    out = net(batch)
+    loss_out = loss_fn(out, batch)
+    loss_out["loss"].backward()
+    torch.cuda.synchronize()
+
+    # loss (lanegcn.py:740-821)
+    assert loss_out["num_cls"] == int(train_golden["loss/num_cls"])
+    assert loss_out["num_reg"] == int(train_golden["loss/num_reg"])
+    for k in ("cls_loss", "reg_loss", "loss"):
+        assert float(loss_out[k]) == pytest.approx(float(train_golden["loss/" + k]), rel=2e-5), k
+
+    # every parameter receives a gradient of the reference's magnitude
+    names = json.load(open(os.path.join(GOLDEN_DIR, "param_names.json")))
+    params = dict(net.named_parameters())
+    assert list(params) == names
+    norms = np.array([float(params[n].grad.norm()) if params[n].grad is not None else -1.0 for n in names])
+    ref_norms = train_golden["grad_norms"]
+    assert (norms >= 0).all()
+    bad = [(n, a, b) for n, a, b in zip(names, norms, ref_norms) if abs(a - b) > 2e-3 * b + 1e-6]
+    assert not bad, bad[:5]
+
+    # selected gradients element-wise (max error relative to the tensor's largest entry).  Gradients are only
+    # piecewise smooth: in f32 mode ONE of the 62,208 ReLU inputs at the A2M.meta output of this fixture has a
+    # reference pre-activation of 4.6e-7 and lands on the other side of zero (tools/debug_mask.py), which moves a
+    # few upstream entries by ~3e-3 of the tensor scale; the split modes happen not to flip it (all <= 4e-6).
+    worst = {}
+    for key, ref in train_golden.items():
+        if key.startswith("grad/"):
+            n = key[5:]
+            worst[n] = rel_err(params[n].grad.cpu().numpy(), ref)
+    bar = 5e-3 if mma == "f32" else 1e-4
+    assert max(worst.values()) <= bar, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+
+    # Adam step through the Optimizer wrapper (utils.py:98-162): lr schedule + update
+    opt = M.Optimizer(net.parameters(), M.config)
+    assert opt.step(0.0) == float(train_golden["lr"])
+    for key, ref in train_golden.items():
+        if key.startswith("after/"):
+            got = params[key[6:]].detach().cpu().numpy()
+            close = np.isclose(got, ref, atol=2e-5, rtol=1e-4)
+            # Adam's first step is lr * g / (|g| + 1e-8): entries whose gradient is ~1e-8 amplify the f32-mode
+            # mask flip above into a full +-lr move, so there a handful of entries may differ
+            assert close.all() if mma != "f32" else close.mean() >= 0.995, (key, float(close.mean()))
+
+
+def test_training_forward_equals_inference_forward(golden, ref_state_names, mma):
+    """The differentiable composition (grad enabled) and the fused inference kernels compute the same features."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import data as gen
+    from lanegcn_amd import lanegcn as M
+    scenes = load_scenes(golden)
+    net = M.Net(M.config)
+    net.load_state_dict(O.seeded_state(ref_state_names, int(golden["seed"])), strict=True)
+    net = net.cuda()
+    batch = gen.collate_fn(scenes)
+    with torch.no_grad():
+        ref = net(batch)
+    out = net(batch)
+    for i in range(len(scenes)):
+        assert float((out["cls"][i] - ref["cls"][i]).abs().max()) <= 2e-4
+        assert torch.allclose(out["reg"][i], ref["reg"][i], rtol=1e-6, atol=5e-4)
+
+
+def test_wgrad_and_gn_bwd_against_autograd(mma):
+    """The two backward kernels alone against stock autograd on random data (fp32, 1e-4 relative)."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import _lib as L
+    from lanegcn_amd import ops
+    torch.manual_seed(0)
+    n = 1000
+    x = torch.randn(n, 128, device="cuda")
+    dy = torch.randn(n, 128, device="cuda")
+    g = torch.randn(128, device="cuda").abs() + 0.5
+    b = torch.randn(128, device="cuda")
+    res = torch.randn(n, 128, device="cuda")
+    # reference on the CPU in fp64: the stock GPU GroupNorm backward is wrong for > 128 rows on this stack
+    # (tools/check_aten_gn.py), which is exactly why the product has its own
+    xr = x.cpu().double().requires_grad_(True)
+    gr, br, rr = (t.cpu().double().requires_grad_(True) for t in (g, b, res))
+    out = torch.relu(torch.nn.functional.group_norm(xr, 1, gr, br, 1e-5) + rr)
+    out.backward(dy.cpu().double())
+    mine = ops.gn_fwd(x, (g, b), res, True)
+    assert float((mine.cpu() - out.detach().float()).abs().max()) <= 1e-5
+    dx, gg, dgam, dbet = ops.gn_bwd(dy, x, mine, g, want_g=True)
+    assert rel_err(dx.cpu().numpy(), xr.grad.cpu().numpy()) <= 1e-4
+    assert rel_err(gg.cpu().numpy(), rr.grad.cpu().numpy()) <= 1e-6
+    assert rel_err(dgam.cpu().numpy(), gr.grad.cpu().numpy()) <= 1e-4
+    assert rel_err(dbet.cpu().numpy(), br.grad.cpu().numpy()) <= 1e-4
+    # wgrad, IDENT relation: dW = dT^T X
+    dW = ops.wgrad(n, [ops.RelSpec(x, None, L.REL_IDENT)], dy)[0]
+    want = dy.double().t() @ x.double()
+    assert rel_err(dW.cpu().numpy(), want.float().cpu().numpy()) <= 1e-5
+
+
+def _torch_lane_conv(x, us, vs, W_ctr, W_rel, g1, b1, W2, g2, b2):
+    """Stock-autograd statement of one LaneConv layer (lanegcn.py:331-362)."""
+    F = torch.nn.functional
+    t = F.linear(x, W_ctr)
+    for u, v, w in zip(us, vs, W_rel):
+        t = t.index_add(0, u, F.linear(x[v], w))
+    y = torch.relu(F.group_norm(t, 1, g1, b1, 1e-5))
+    z = F.group_norm(F.linear(y, W2), 1, g2, b2, 1e-5)
+    return torch.relu(z + x)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("n", [70, 486])
+def test_lane_conv_fn_gradients_vs_stock_autograd(mode, n):
+    """LaneConvFn (fused HIP forward, composed HIP backward) against stock autograd in fp64 on a random
+    multigraph: output, d input and every parameter gradient within 1e-4 of the tensor's scale."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import _lib as L
+    from lanegcn_amd import autograd as A
+    from lanegcn_amd import ops
+    prev = ops.get_mma()
+    ops.set_mma(mode)
+    try:
+        g = torch.Generator().manual_seed(n)
+        rnd = lambda *s: torch.randn(*s, generator=g)
+        us = [torch.randint(0, n, (m,), generator=g) for m in (3 * n, n, 0, n // 2)]
+        vs = [torch.randint(0, n, (len(u),), generator=g) for u in us]
+        x = rnd(n, 128)
+        Ws = [rnd(128, 128) * 0.08 for _ in range(6)]       # ctr, 4 relations, ctr2
+        gs = [torch.rand(128, generator=g) + 0.5 for _ in range(2)]
+        bs = [rnd(128) * 0.1 for _ in range(2)]
+        d_out = rnd(n, 128)
+        # stock autograd in fp64 on the CPU
+        P = [t.double().requires_grad_(True) for t in [x] + Ws + gs + bs]
+        xr, wr, gr, br = P[0], P[1:7], P[7:9], P[9:11]
+        ref = _torch_lane_conv(xr, us, vs, wr[0], wr[1:5], gr[0], br[0], wr[5], gr[1], br[1])
+        ref.backward(d_out.double())
+        # HIP
+        D = [t.cuda().requires_grad_(True) for t in [x] + Ws + gs + bs]
+        xd, wd, gd, bd = D[0], D[1:7], D[7:9], D[9:11]
+        ud, vd = [u.cuda() for u in us], [v.cuda() for v in vs]
+        plan, plan_t = ops.csr_build(ud, vd, n), ops.csr_build(vd, ud, n)
+        rels, weights = [A.Rel(0, 0, L.REL_IDENT)], [wd[0]]
+        for r in range(4):
+            if plan.n_edges[r] > 0:
+                rels.append(A.Rel(0, len(weights), L.REL_CSR, r))
+                weights.append(wd[1 + r])
+        spec = A.BlockSpec(n_rows=n, rels=rels, gn=True, relu=True, has_res=True, plan=plan, plan_t=plan_t)
+        out = A.LaneConvFn.apply(spec, xd, gd[0], bd[0], wd[5], gd[1], bd[1], *weights)
+        out.backward(d_out.cuda())
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().float().numpy()) <= 1e-4
+        names = ["x", "W_ctr", "W_r0", "W_r1", "W_r2(empty)", "W_r3", "W_ctr2", "g1", "g2", "b1", "b2"]
+        for name, a, b in zip(names, D, P):
+            if name == "W_r2(empty)":
+                assert a.grad is None or float(a.grad.abs().max()) == 0.0
+                continue
+            assert rel_err(a.grad.cpu().numpy(), b.grad.float().numpy()) <= 1e-4, (mode, name)
+    finally:
+        ops.set_mma(prev)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+@pytest.mark.parametrize("n", [42, 486, 1000])
+def test_row_block_gradients_vs_stock_autograd(mode, n):
+    """linear_gn (IDENT relation, GN, ReLU, residual) and a weight-slice block against fp64 autograd."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import autograd as A
+    from lanegcn_amd import ops
+    F = torch.nn.functional
+    prev = ops.get_mma()
+    ops.set_mma(mode)
+    try:
+        g = torch.Generator().manual_seed(n + 1)
+        x, res, d_out = (torch.randn(n, 128, generator=g) for _ in range(3))
+        W = torch.randn(128, 132, generator=g) * 0.1
+        gam, bet = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+        P = [t.double().requires_grad_(True) for t in (x, W, gam, bet, res)]
+        ref = torch.relu(F.group_norm(F.linear(P[0], P[1][:, :128]), 1, P[2], P[3], 1e-5) + P[4])
+        ref.backward(d_out.double())
+        D = [t.cuda().requires_grad_(True) for t in (x, W, gam, bet, res)]
+        gn = torch.nn.GroupNorm(1, 128).cuda()
+        gn.weight, gn.bias = torch.nn.Parameter(D[2].detach().clone()), torch.nn.Parameter(D[3].detach().clone())
+        out = A.linear_gn(D[0], D[1], gn=gn, relu=True, res=D[4], col0=0)
+        out.backward(d_out.cuda())
+        assert rel_err(out.detach().cpu().numpy(), ref.detach().float().numpy()) <= 1e-4
+        got = [D[0].grad, D[1].grad, gn.weight.grad, gn.bias.grad, D[4].grad]
+        for name, a, b in zip(["x", "W", "gamma", "beta", "res"], got, P):
+            assert rel_err(a.cpu().numpy(), b.grad.float().numpy()) <= 1e-4, (mode, n, name)
+    finally:
+        ops.set_mma(prev)

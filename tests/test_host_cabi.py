@@ -43,7 +43,7 @@ def test_struct_layout_matches_header(lib):
     # lgcn_rel_t: 2 pointers + 2 int32; lgcn_agg_mlp_t: 24-byte head, 16 rels, 14 pointers
     assert C.sizeof(mod.Rel) == 24
     assert mod.AggMlp.rel.offset == 32
-    assert C.sizeof(mod.AggMlp) == 32 + 16 * 24 + 14 * 8
+    assert C.sizeof(mod.AggMlp) == 32 + 16 * 24 + 16 * 8
 
 
 def test_size_helpers(lib):
