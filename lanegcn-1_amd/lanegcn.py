@@ -460,6 +460,17 @@ class A2A(nn.Module):
 
 
 # ------------------------------------------------------------------ rest of the plugin (outside the hot path)
+def upsample2_linear(x: Tensor) -> Tensor:
+    """F.interpolate(x, scale_factor=2, mode="linear", align_corners=False) on [N, C, L] written with slices:
+    out[2i] = 0.25 x[i-1] + 0.75 x[i], out[2i+1] = 0.75 x[i] + 0.25 x[i+1] (edges clamped).  The stock ROCm
+    upsample_linear1d kernels take 30 ms forward / 81 ms backward at [1600,128,10] on MI355X (88 % of a training
+    step); this is a handful of elementwise ops."""
+    left = torch.cat((x[..., :1], x[..., :-1]), -1)
+    right = torch.cat((x[..., 1:], x[..., -1:]), -1)
+    even, odd = 0.25 * left + 0.75 * x, 0.75 * x + 0.25 * right
+    return torch.stack((even, odd), -1).reshape(*x.shape[:-1], 2 * x.shape[-1])
+
+
 class ActorNet(nn.Module):
     """1-D conv FPN over the 20-step actor tracks (reference lanegcn.py:212-263); stock ATen ops."""
 
@@ -485,8 +496,7 @@ class ActorNet(nn.Module):
             pyramid.append(out)
         out = self.lateral[-1](pyramid[-1])
         for i in range(len(pyramid) - 2, -1, -1):
-            out = F.interpolate(out, scale_factor=2, mode="linear", align_corners=False)
-            out = out + self.lateral[i](pyramid[i])
+            out = upsample2_linear(out) + self.lateral[i](pyramid[i])
         return self.output(out)[:, :, -1]
 
 

@@ -88,3 +88,13 @@ class Optimizer(object):
 
     def state_dict(self):
         return self.opt.state_dict()
+
+
+def load_pretrain(net, pretrain_dict):
+    """Copy every tensor whose name AND shape match into `net` (reference utils.py:51-59): this is what lets
+    the published 36.000.ckpt load into this build's modules."""
+    state = net.state_dict()
+    for key, value in pretrain_dict.items():
+        if key in state and value.size() == state[key].size():
+            state[key] = value if isinstance(value, torch.Tensor) else value.data
+    net.load_state_dict(state)

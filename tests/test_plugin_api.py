@@ -79,3 +79,11 @@ def test_synthetic_workload_sizes():
     e1 = sum(len(d["u"]) for d in g["pre"] + g["suc"]) + 2 * len(g["left"]["u"])
     assert (g["num_nodes"], e1) == (10008, 59952)
     assert gen.synth_batch("S0", seed=0)[0]["graph"]["num_nodes"] == 648
+
+
+def test_upsample2_linear_is_interpolate(M):
+    import torch.nn.functional as F
+    for shape in ((7, 5, 10), (3, 4, 5), (2, 1, 1)):
+        x = torch.randn(*shape)
+        want = F.interpolate(x, scale_factor=2, mode="linear", align_corners=False)
+        assert torch.allclose(M.upsample2_linear(x), want, atol=1e-6)
