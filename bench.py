@@ -269,7 +269,7 @@ def main():
         if single is not None:
             line["single_stream"] = {"value": args.gpus * n_scenes * args.steps / single, "unit": "scenes/s",
                                      "ms_per_step": single / args.steps * 1e3}
-        if args.cpu_seconds > 0:
+        if args.cpu_seconds > 0 and world == 1:      # reported baseline: rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(scenes, actors_cpu, mods, args.cpu_seconds)
             line["speedup_vs_cpu_all_cores"] = line["value"] / args.gpus / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)

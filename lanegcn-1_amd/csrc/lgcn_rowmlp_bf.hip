@@ -765,9 +765,10 @@ static void launch_agg(const lgcn_agg_mlp_t &p, int rb, bool lane_conv, hipStrea
 static int fmt_of(int mma) { return mma == LGCN_MMA_BF16X3 ? 0 : mma == LGCN_MMA_F16X2 ? 1 : 2; }
 
 int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st) {
-    static const int force_rb = env_int("LGCN_RB", 0), ring = env_int("LGCN_RING", 1);
+    static const int force_rb = env_int("LGCN_RB", 0), force_rb_lc = env_int("LGCN_RB_LC", 0), ring = env_int("LGCN_RING", 1);
     int rb = p.tile_rb;
     if (rb < 0 || rb > 4) return LGCN_EINVAL;
+    if (rb == 0 && lane_conv && force_rb_lc >= 1 && force_rb_lc <= 4) rb = force_rb_lc;
     if (rb == 0) rb = force_rb >= 1 && force_rb <= 4 ? force_rb : pick_rb(p.n_rows, 1);
     const bool deep = ring >= 3;
     switch (fmt_of(p.mma)) {

@@ -90,7 +90,7 @@ def collate_flat(scenes: List[Dict], device=None) -> FlatBatch:
 
     def up(a, dtype=None):
         t = torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype)))
-        return t.pin_memory().to(dev, non_blocking=True)
+        return t if dev.type == "cpu" else t.pin_memory().to(dev, non_blocking=True)
 
     cat = lambda key, src: np.concatenate([npy(s[key]) for s in src], 0)
     return FlatBatch(
