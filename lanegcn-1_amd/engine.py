@@ -110,16 +110,37 @@ class HotPathEngine:
     """graph_gather -> MapNet -> A2M -> M2M -> M2A -> A2A on the HIP kernels, sync-free."""
 
     def __init__(self, map_net: M.MapNet, a2m: M.A2M, m2m: M.M2M, m2a: M.M2A, a2a: M.A2A, config=None,
-                 legacy_offsets: bool = True):
+                 legacy_offsets: bool = True, branches: bool = False):
         self.map_net, self.a2m, self.m2m, self.m2a, self.a2a = map_net, a2m, m2m, m2a, a2a
         self.config = config or M.config
         self.legacy_offsets = legacy_offsets
+        # optional parallel graph branches: the three pair searches (index work that depends only on the centres)
+        # and every Att's V GEMM on a side stream, forked / joined with events (captured as graph edges).
+        # Measured on MI355X / ROCm 7.2: bitwise the same result, no single-stream gain (38.9 k vs 39.4 k
+        # scenes/s) and a loss with four graphs in flight (61 k vs 90 k) -> off by default.
+        self.branches = branches
+        self._side = None
 
     @torch.no_grad()
     def forward(self, fb: FlatBatch, actors: torch.Tensor, stages: bool = False) -> Dict[str, torch.Tensor]:
         """actors: [A,128] ActorNet output.  Returns {"nodes", "actors"} (+ every stage if stages)."""
         cfg = self.config
         out = {}
+        main = torch.cuda.current_stream()
+        side = None
+        if self.branches:
+            if self._side is None:
+                self._side = torch.cuda.Stream()
+            side = self._side
+        dev = fb.node_ctrs.device
+        searches = ((fb.node_ctrs, fb.node_off, fb.actor_ctrs, fb.actor_off, cfg["actor2map_dist"], fb.cap_a2m),
+                    (fb.actor_ctrs, fb.actor_off, fb.node_ctrs, fb.node_off, cfg["map2actor_dist"], fb.cap_a2m),
+                    (fb.actor_ctrs, fb.actor_off, fb.actor_ctrs, fb.actor_off, cfg["actor2actor_dist"], fb.cap_a2a))
+        bufs = [ops.pairs_alloc(s[0].shape[0], fb.n_scenes, s[5], dev) for s in searches]   # on the main stream
+        if side is not None:
+            side.wait_stream(main)
+        with torch.cuda.stream(side if side is not None else main):
+            pairs = [ops.pairs_build(*s, self.legacy_offsets, bufs=b) for s, b in zip(searches, bufs)]
         # graph_gather (lanegcn.py:171-209) + CSR plan
         g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
         us = [g64[a:b] for (a, b), _ in fb.rel_slices]
@@ -132,10 +153,10 @@ class HotPathEngine:
             out["map_net"] = feat
         # A2M (lanegcn.py:385-407)
         feat = self.a2m.fuse_meta(feat, fb.turn, fb.control, fb.intersect)
-        ps = ops.pairs_build(fb.node_ctrs, fb.node_off, fb.actor_ctrs, fb.actor_off, cfg["actor2map_dist"],
-                             fb.cap_a2m, self.legacy_offsets)
+        if side is not None:
+            main.wait_stream(side)            # the pair sets are needed from here on
         for att in self.a2m.att:
-            feat = att.run(feat, actors, ps)
+            feat = att.run(feat, actors, pairs[0], side)
         if stages:
             out["a2m"] = feat
         # M2M (lanegcn.py:445-480)
@@ -143,18 +164,14 @@ class HotPathEngine:
         if stages:
             out["m2m"] = feat
         # M2A (lanegcn.py:502-513)
-        ps = ops.pairs_build(fb.actor_ctrs, fb.actor_off, fb.node_ctrs, fb.node_off, cfg["map2actor_dist"],
-                             fb.cap_a2m, self.legacy_offsets)
         act = actors
         for att in self.m2a.att:
-            act = att.run(act, feat, ps)
+            act = att.run(act, feat, pairs[1], side)
         if stages:
             out["m2a"] = act
         # A2A (lanegcn.py:534-545)
-        ps = ops.pairs_build(fb.actor_ctrs, fb.actor_off, fb.actor_ctrs, fb.actor_off, cfg["actor2actor_dist"],
-                             fb.cap_a2a, self.legacy_offsets)
         for att in self.a2a.att:
-            act = att.run(act, act, ps)
+            act = att.run(act, act, pairs[2], side)
         if stages:
             out["a2a"] = act
         out["nodes"], out["actors"] = feat, act

@@ -366,16 +366,27 @@ class Att(nn.Module):
                         [A.Rel(0, 0, L.REL_IDENT), A.Rel(1, 1, L.REL_RANGE)], T, gn=self.norm, relu=True, **spec_kw)
         return A.linear_gn(y, lin.linear.weight, gn=lin.norm, relu=True, res=agts)
 
-    def run(self, agts: Tensor, ctx: Tensor, ps: ops.PairSet) -> Tensor:
-        """The pair MLP + segment reduce + node epilogue for a given pair set (lanegcn.py:691-709)."""
+    def run(self, agts: Tensor, ctx: Tensor, ps: ops.PairSet, side: Optional[torch.cuda.Stream] = None) -> Tensor:
+        """The pair MLP + segment reduce + node epilogue for a given pair set (lanegcn.py:691-709).
+        `side`: a second stream for V (independent of U) -- fork/join around it, buffers allocated here."""
         T = agts.shape[0]
         lin = self.linear
         c0 = self.ctx[0]
         # row-wise Linears commute with the gathers agts[hi] / ctx[wi]: evaluate them per node
+        wv = ops.packed(c0.linear.weight, 256, 128)
+        if side is not None:
+            main = torch.cuda.current_stream()
+            V = torch.empty((ctx.shape[0], ops.C_FEAT), dtype=torch.float32, device=ctx.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ops.agg_mlp(ctx.shape[0], [ops.RelSpec(ctx, wv)], 0, out=V)
         U = ops.agg_mlp(T, [ops.RelSpec(agts, ops.packed(self.query.linear.weight))],
                         L.F_GN1 | L.F_RELU1 | L.F_GEMM2, gn1=_gn(self.query.norm),
                         wp2=ops.packed(c0.linear.weight, 128, 128), eps=self.query.norm.eps)
-        V = ops.agg_mlp(ctx.shape[0], [ops.RelSpec(ctx, ops.packed(c0.linear.weight, 256, 128))], 0)
+        if side is not None:
+            main.wait_stream(side)
+        else:
+            V = ops.agg_mlp(ctx.shape[0], [ops.RelSpec(ctx, wv)], 0)
         m = ops.att_pairs(ps, self.dist[0].weight, self.dist[0].bias, ops.packed(self.dist[2].linear.weight),
                           _gn(self.dist[2].norm), ops.packed(c0.linear.weight, 0, 128), U, V, _gn(c0.norm),
                           eps=c0.norm.eps)

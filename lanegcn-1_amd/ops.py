@@ -166,8 +166,17 @@ class PairSet:
         return h[:P], w[:P]
 
 
+def pairs_alloc(n_agt: int, n_scenes: int, cap: int, device):
+    """Output / workspace buffers of pairs_build (allocate them on the stream that will consume the pairs when
+    the search itself is enqueued on another stream)."""
+    lib = L.load()
+    i32 = dict(dtype=torch.int32, device=device)
+    return (torch.empty(max(cap, 1), **i32), torch.empty(max(cap, 1), **i32), torch.empty(1, **i32),
+            torch.empty(n_agt + 1, **i32), torch.empty(lib.lgcn_pairs_ws_elems(n_agt, n_scenes), **i32))
+
+
 def pairs_build(agt_ctrs: torch.Tensor, agt_off: torch.Tensor, ctx_ctrs: torch.Tensor, ctx_off: torch.Tensor,
-                dist_th: float, cap: int, legacy_offsets: bool = True) -> PairSet:
+                dist_th: float, cap: int, legacy_offsets: bool = True, bufs=None) -> PairSet:
     lib = L.load()
     agt_ctrs = _dev(agt_ctrs, torch.float32, "agt_ctrs")
     ctx_ctrs = _dev(ctx_ctrs, torch.float32, "ctx_ctrs")
@@ -177,12 +186,7 @@ def pairs_build(agt_ctrs: torch.Tensor, agt_off: torch.Tensor, ctx_ctrs: torch.T
     if ctx_off.numel() != B + 1 or B < 1:
         raise L.LgcnError("pairs_build: offset tables must both have B+1 entries")
     T, S = agt_ctrs.shape[0], ctx_ctrs.shape[0]
-    dev = agt_ctrs.device
-    hi = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
-    wi = torch.empty(max(cap, 1), dtype=torch.int32, device=dev)
-    n_pairs = torch.empty(1, dtype=torch.int32, device=dev)
-    rowptr = torch.empty(T + 1, dtype=torch.int32, device=dev)
-    ws = torch.empty(lib.lgcn_pairs_ws_elems(T, B), dtype=torch.int32, device=dev)
+    hi, wi, n_pairs, rowptr, ws = bufs if bufs is not None else pairs_alloc(T, B, cap, agt_ctrs.device)
     L.check(lib.lgcn_pairs_build(_ptr(agt_ctrs), _ptr(agt_off), _ptr(ctx_ctrs), _ptr(ctx_off), B, T, S,
                                  float(dist_th), int(bool(legacy_offsets)), _ptr(hi), _ptr(wi), cap,
                                  _ptr(n_pairs), _ptr(rowptr), _ptr(ws), _stream()), "lgcn_pairs_build")

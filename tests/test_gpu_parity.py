@@ -373,3 +373,29 @@ def test_tile_heights_agree(hip, ref_state_names):
         outs = [M.lane_conv(mods["map_net"].fuse, feat, plan, 6, tile_rb=rb).cpu().numpy() for rb in (1, 2, 3, 4)]
     for o in outs[1:]:
         assert np.array_equal(outs[0], o)
+
+
+def test_engine_matches_modules_and_graph_replay(hip, ref_state_names):
+    """The flat-batch engine (side-stream branches on and off, eager and hipGraph replay) gives bitwise the
+    features of the module-level path."""
+    M, _ = hip
+    from lanegcn_amd import data as gen
+    from lanegcn_amd.engine import HotPathEngine, collate_flat
+    sd = O.seeded_state(ref_state_names, 11)
+    mods = make_modules(M, sd)
+    scenes_np = gen.synth_batch("S2", seed=2, n_scenes=5)
+    scenes = [to_torch_scene(s) for s in scenes_np]
+    actors = torch.from_numpy(np.random.default_rng(1).normal(0, 1, (250, 128)).astype(np.float32)).relu()
+    want, _ = run_hot_path(M, mods, scenes, actors)
+    fb = collate_flat(scenes_np)
+    for branches in (False, True):
+        eng = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"], branches=branches)
+        out = eng.forward(fb, actors.cuda(), stages=True)
+        torch.cuda.synchronize()
+        for k in ("map_net", "a2m", "m2m", "m2a", "a2a"):
+            assert np.array_equal(out[k].cpu().numpy(), want[k]), (branches, k)
+        graph, gout = eng.capture(fb, actors.cuda())
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(gout["nodes"].cpu().numpy(), want["m2m"]) and np.array_equal(gout["actors"].cpu().numpy(), want["a2a"])
