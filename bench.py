@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="S2", choices=["S0", "S1", "S2"])
     ap.add_argument("--scenes", type=int, default=None, help="override scenes per batch (S2: 32)")
+    ap.add_argument("--mapnet-only", action="store_true",
+                    help="step = graph_gather + CSR plan + MapNet only (BASELINE config 'MapNet LaneConv only', use with S1)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--streams", type=int, default=4,
@@ -170,11 +172,11 @@ def main():
 
     log("rank %d: batch ready (N=%d nodes, A=%d actors, sumE=%d)" % (rank, fb.n_nodes, fb.n_actors, sum(fb.n_edges)))
     if args.no_graph:
-        step = lambda: eng.forward(fb, actors)
+        step = lambda: eng.forward(fb, actors, mapnet_only=args.mapnet_only)
         for _ in range(3):
             step()
     elif args.streams <= 1:
-        graph, _ = eng.capture(fb, actors)
+        graph, _ = eng.capture(fb, actors, mapnet_only=args.mapnet_only)
         step = graph.replay
     else:
         # S independent batches, one captured forward each, replayed round-robin on S streams: step k runs
@@ -184,7 +186,7 @@ def main():
             sc = scenes if j == 0 else gen.synth_batch(args.workload, seed=100 + rank + 1000 * j, n_scenes=args.scenes)
             fbj = fb if j == 0 else collate_flat(sc, dev)
             aj = actors if j == 0 else torch.randn(fbj.n_actors, C, device=dev).relu()
-            gj, _ = eng.capture(fbj, aj)
+            gj, _ = eng.capture(fbj, aj, mapnet_only=args.mapnet_only)
             lanes.append((torch.cuda.Stream(), gj))
         counter = [0]
 
@@ -224,10 +226,10 @@ def main():
     # per-kernel durations (HIP events on the launch stream), eager launches of the same forward
     with ops.kernel_timer() as kt:
         for _ in range(10):
-            eng.forward(fb, actors)
+            eng.forward(fb, actors, mapnet_only=args.mapnet_only)
     ksum = kt.summary()
     if rank == 0:
-        st = eng.forward(fb, actors, stages=True)
+        st = eng.forward(fb, actors, stages=not args.mapnet_only, mapnet_only=args.mapnet_only)
         torch.cuda.synchronize()
         assert all(torch.isfinite(v).all() for v in st.values())
 
@@ -237,6 +239,12 @@ def main():
         lc_ms = float(np.mean(ksum["laneconv"]))
         flops, byts = laneconv_algorithmic(fb.n_nodes, sum_e)
         ach = flops / (lc_ms * 1e-3) / 1e12
+        how = "eager" if args.no_graph else "hipGraph replay" + (
+            "" if args.streams <= 1 else ", %d forwards in flight on %d streams" % (args.streams, args.streams))
+        what = ("MapNet only (graph_gather+CSR plan+stem+4 LaneConv)" if args.mapnet_only
+                else "hot path forward (graph_gather+CSR plan+MapNet+A2M+M2M+M2A+A2A)")
+        workload_desc = ("%s: %s, %d scenes/GPU, %d lane nodes, %d edges, %d actors, random-init weights, inputs "
+                         "resident in HBM, %s" % (args.workload, what, n_scenes, fb.n_nodes, sum_e, fb.n_actors, how))
         line = {
             "metric": "Argoverse scenes/sec forward (batch=32, ~10k lane nodes)",
             "value": args.gpus * n_scenes * args.steps / elapsed,
@@ -245,13 +253,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if mma == "bf16" else "f32", "mma": mma, "data": "synthetic",
-            "config": {"workload": "%s: hot path forward (graph_gather+CSR plan+MapNet+A2M+M2M+M2A+A2A), "
-                                   "%d scenes/GPU, %d lane nodes, %d edges, %d actors, random-init weights, "
-                                   "inputs resident in HBM, %s" % (args.workload, n_scenes, fb.n_nodes, sum_e,
-                                                                    fb.n_actors,
-                                                                    "eager" if args.no_graph else "hipGraph replay" + (
-                                                                        "" if args.streams <= 1 else
-                                                                        ", %d forwards in flight on %d streams" % (args.streams, args.streams))),
+            "config": {"workload": workload_desc,
                        "scenes_per_gpu": n_scenes, "parallelism": "dp%d (independent scene shards)" % args.gpus},
             "roofline": {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_TFLOPS[mma], "unit": "TFLOP/s",

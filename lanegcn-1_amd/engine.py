@@ -122,8 +122,16 @@ class HotPathEngine:
         self._side = None
 
     @torch.no_grad()
-    def forward(self, fb: FlatBatch, actors: torch.Tensor, stages: bool = False) -> Dict[str, torch.Tensor]:
-        """actors: [A,128] ActorNet output.  Returns {"nodes", "actors"} (+ every stage if stages)."""
+    def forward(self, fb: FlatBatch, actors: torch.Tensor, stages: bool = False,
+                mapnet_only: bool = False) -> Dict[str, torch.Tensor]:
+        """actors: [A,128] ActorNet output.  Returns {"nodes", "actors"} (+ every stage if stages).
+        mapnet_only: stop after MapNet (BASELINE config "MapNet LaneConv only"): graph_gather + plan + MapNet."""
+        if mapnet_only:
+            g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
+            plan = ops.csr_build([g64[a:b] for (a, b), _ in fb.rel_slices], [g64[a:b] for _, (a, b) in fb.rel_slices],
+                                 fb.n_nodes)
+            feat = M.lane_conv(self.map_net.fuse, self.map_net.stem(fb.node_ctrs, fb.node_feats), plan, fb.num_scales)
+            return {"nodes": feat, "actors": actors}
         cfg = self.config
         out = {}
         main = torch.cuda.current_stream()
@@ -177,17 +185,17 @@ class HotPathEngine:
         out["nodes"], out["actors"] = feat, act
         return out
 
-    def capture(self, fb: FlatBatch, actors: torch.Tensor, warmup: int = 2):
+    def capture(self, fb: FlatBatch, actors: torch.Tensor, warmup: int = 2, **fwd_kw):
         """Capture one forward into a hipGraph.  Returns (graph, outputs); ``graph.replay()`` re-runs
         the whole forward on the captured buffers (refill fb's tensors / `actors` in place first)."""
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                self.forward(fb, actors)       # also fills the weight-pack caches outside the capture
+                self.forward(fb, actors, **fwd_kw)   # also fills the weight-pack caches outside the capture
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            out = self.forward(fb, actors)
+            out = self.forward(fb, actors, **fwd_kw)
         return graph, out
