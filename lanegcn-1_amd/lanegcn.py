@@ -522,9 +522,20 @@ class AttDest(nn.Module):
     def forward(self, agts: Tensor, agt_ctrs: Tensor, dest_ctrs: Tensor) -> Tensor:
         n_agt, num_mods = agts.size(1), dest_ctrs.size(1)
         d = (agt_ctrs.unsqueeze(1) - dest_ctrs).reshape(-1, 2)
-        h = F.relu(self.dist[0](d))
-        d = group_norm1(F.linear(h, self.dist[2].linear.weight), self.dist[2].norm, relu=True)
+        h = F.relu(self.dist[0](d))                                   # nn.Linear(2,128): [rows,2]-shaped, stock op
         a = agts.unsqueeze(1).expand(-1, num_mods, -1).reshape(-1, n_agt)
+        if agts.is_cuda and n_agt == ops.C_FEAT:
+            # dist.2 = Linear+GN+ReLU (one row block); agt = Linear(256 -> 128)+GN+ReLU over cat(dist, agts) = a
+            # two-relation row block on the two 128-column halves of its weight (no cat)
+            d = A.linear_gn(h, self.dist[2].linear.weight, gn=self.dist[2].norm, relu=True) \
+                if ops.wants_grad(h, *self.dist[2].parameters()) else self.dist[2](h)
+            w, a = self.agt.linear.weight, a.contiguous()
+            if ops.wants_grad(d, a, *self.agt.parameters()):
+                return A.row_block([d, a], [w], [A.Rel(0, 0, L.REL_IDENT, 0, 0), A.Rel(1, 0, L.REL_IDENT, 0, 128)],
+                                   d.shape[0], gn=self.agt.norm, relu=True)
+            return ops.agg_mlp(d.shape[0], [ops.RelSpec(d, ops.packed(w, 0, 128)), ops.RelSpec(a, ops.packed(w, 128, 128))],
+                               L.F_GN1 | L.F_RELU1, gn1=_gn(self.agt.norm), eps=self.agt.norm.eps)
+        d = group_norm1(F.linear(h, self.dist[2].linear.weight), self.dist[2].norm, relu=True)
         return self.agt(torch.cat((d, a), 1))
 
 

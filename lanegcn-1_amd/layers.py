@@ -131,7 +131,25 @@ class LinearRes(nn.Module):
         else:
             self.transform = None
 
+    def _hot_shaped(self, x):
+        return (x.is_cuda and x.dim() == 2 and self.transform is None and self.linear1.in_features == ops.C_FEAT
+                and self.linear1.out_features == ops.C_FEAT and isinstance(self.norm1, nn.GroupNorm)
+                and self.norm1.num_groups == 1)
+
     def forward(self, x):
+        if self._hot_shaped(x):
+            # 128 -> 128: the fused two-stage row block of the hot path (one launch; PredNet heads, lanegcn.py:587-600)
+            from . import autograd as A
+            x = x.contiguous()
+            if ops.wants_grad(x, *self.parameters()):
+                spec = A.BlockSpec(n_rows=x.shape[0], rels=[A.Rel(0, 0, L.REL_IDENT)], gn=True, relu=True, has_res=True,
+                                   eps=self.norm1.eps)
+                return A.LaneConvFn.apply(spec, x, self.norm1.weight, self.norm1.bias, self.linear2.weight,
+                                          self.norm2.weight, self.norm2.bias, self.linear1.weight)
+            full = L.F_GN1 | L.F_RELU1 | L.F_GEMM2 | L.F_GN2 | L.F_RES | L.F_RELU2
+            return ops.agg_mlp(x.shape[0], [ops.RelSpec(x, ops.packed(self.linear1.weight))], full,
+                               gn1=(self.norm1.weight, self.norm1.bias), wp2=ops.packed(self.linear2.weight),
+                               gn2=(self.norm2.weight, self.norm2.bias), res=x, eps=self.norm1.eps)
         out = group_norm1(self.linear1(x), self.norm1, relu=True)
         out = group_norm1(self.linear2(out), self.norm2)
         if self.transform is not None:

@@ -53,7 +53,7 @@ def test_training_step_matches_reference(golden, train_golden, ref_state_names, 
     assert loss_out["num_cls"] == int(train_golden["loss/num_cls"])
     assert loss_out["num_reg"] == int(train_golden["loss/num_reg"])
     for k in ("cls_loss", "reg_loss", "loss"):
-        assert float(loss_out[k]) == pytest.approx(float(train_golden["loss/" + k]), rel=2e-5), k
+        assert float(loss_out[k].detach()) == pytest.approx(float(train_golden["loss/" + k]), rel=2e-5), k
 
     # every parameter receives a gradient of the reference's magnitude
     names = json.load(open(os.path.join(GOLDEN_DIR, "param_names.json")))

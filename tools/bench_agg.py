@@ -44,7 +44,7 @@ def timeit(fn, reps=20, rounds=5):
 
 
 def main():
-    modes = sys.argv[1:] or ["f32", "bf16x3", "bf16"]
+    modes = sys.argv[1:] or ["f32", "bf16x3", "f16x2", "bf16"]
     torch.manual_seed(0)
     net = M.MapNet(M.config).cuda().eval()
     fb = collate_flat(gen.synth_batch("S2", seed=100))
@@ -89,9 +89,10 @@ def main():
             print("  1 IDENT, no GEMM2/GN    rb=auto: %7.1f us" % run("ident", 1, flags=0))
             if mode != "f32":
                 for rb in (2, 3):
-                    print("  ABLATION rb=%d 15 IDENT: full %6.1f | no in-loop gather %6.1f | no MFMA %6.1f | neither %6.1f us" % (
-                        rb, run("ident", 15, rb=rb), run("ident", 15, flags=full | 256, rb=rb),
-                        run("ident", 15, flags=full | 512, rb=rb), run("ident", 15, flags=full | 768, rb=rb)))
+                    for kind in ("ident", "csr"):
+                        print("  ABLATION rb=%d 15 %s: full %6.1f | no in-loop gather %6.1f | no MFMA %6.1f | neither %6.1f us" % (
+                            rb, kind, run(kind, 15, rb=rb), run(kind, 15, flags=full | 256, rb=rb),
+                            run(kind, 15, flags=full | 512, rb=rb), run(kind, 15, flags=full | 768, rb=rb)))
             print("  8 CSR relations         rb=auto: %7.1f us" % run("csr", 8))
 
 
