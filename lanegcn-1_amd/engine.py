@@ -199,3 +199,56 @@ class HotPathEngine:
         with torch.cuda.graph(graph):
             out = self.forward(fb, actors, **fwd_kw)
         return graph, out
+
+
+class FullNetEngine:
+    """Whole Net.forward (lanegcn.py:127-151) on flat device inputs, capturable in one hipGraph: ActorNet (stock
+    conv ops) -> hot path (HotPathEngine) -> PredNet (HIP row blocks + stock heads) -> world-frame transform."""
+
+    def __init__(self, net: "M.Net"):
+        self.net = net
+        self.hot = HotPathEngine(net.map_net, net.a2m, net.m2m, net.m2a, net.a2a, net.config)
+
+    @staticmethod
+    def actor_inputs(scenes, device=None):
+        """[A,3,20] actor tracks (actor_gather, lanegcn.py:155-168) and the per-actor world-frame transform
+        rot [A,2,2] / orig [A,2] (the scene's, repeated for its actors: no host data inside the captured forward)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        npy = lambda x: x.numpy() if torch.is_tensor(x) else np.asarray(x)
+        feats = np.concatenate([npy(s["feats"]).transpose(0, 2, 1) for s in scenes], 0).astype(np.float32)
+        rot = np.concatenate([np.repeat(npy(s["rot"])[None], len(s["ctrs"]), 0) for s in scenes]).astype(np.float32)
+        orig = np.concatenate([np.repeat(npy(s["orig"])[None], len(s["ctrs"]), 0) for s in scenes]).astype(np.float32)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        return up(feats), up(rot), up(orig)
+
+    @torch.no_grad()
+    def forward(self, fb: FlatBatch, actor_feats: torch.Tensor, rot: torch.Tensor, orig: torch.Tensor,
+                sizes: List[int]) -> Dict[str, torch.Tensor]:
+        """Returns {"cls": [A,6], "reg": [A,6,30,2]} for all actors of the batch (scene i = rows
+        sum(sizes[:i]) .. sum(sizes[:i+1])), reg already in world coordinates."""
+        net = self.net
+        actors = net.actor_net(actor_feats)
+        actors = self.hot.forward(fb, actors)["actors"]
+        idcs, ctrs, st = [], [], 0
+        for n in sizes:
+            idcs.append(slice(st, st + n))
+            ctrs.append(fb.actor_ctrs[st:st + n])
+            st += n
+        out = net.pred_net(actors, idcs, ctrs)
+        reg = torch.cat(out["reg"], 0)
+        cls = torch.cat(out["cls"], 0)
+        reg = torch.einsum("amtk,akj->amtj", reg, rot) + orig.view(-1, 1, 1, 2)
+        return {"cls": cls, "reg": reg}
+
+    def capture(self, fb, actor_feats, rot, orig, sizes, warmup: int = 3):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.forward(fb, actor_feats, rot, orig, sizes)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.forward(fb, actor_feats, rot, orig, sizes)
+        return graph, out

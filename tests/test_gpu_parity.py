@@ -399,3 +399,28 @@ def test_engine_matches_modules_and_graph_replay(hip, ref_state_names):
             graph.replay()
         torch.cuda.synchronize()
         assert np.array_equal(gout["nodes"].cpu().numpy(), want["m2m"]) and np.array_equal(gout["actors"].cpu().numpy(), want["a2a"])
+
+
+def test_full_net_engine_matches_net_forward(golden, ref_state_names, hip):
+    """FullNetEngine (flat inputs, one hipGraph) == Net.forward on the reference's batch format."""
+    M, _ = hip
+    from lanegcn_amd import data as gen
+    from lanegcn_amd.engine import FullNetEngine, collate_flat
+    scenes = load_scenes(golden)
+    net = M.Net(M.config)
+    net.load_state_dict(O.seeded_state(ref_state_names, int(golden["seed"])), strict=True)
+    net = net.cuda().eval()
+    with torch.no_grad():
+        want = net(gen.collate_fn(scenes))
+    eng = FullNetEngine(net)
+    fb = collate_flat(scenes)
+    feats, rot, orig = eng.actor_inputs(scenes)
+    sizes = [len(s["ctrs"]) for s in scenes]
+    graph, out = eng.capture(fb, feats, rot, orig, sizes)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert float((out["cls"] - torch.cat(want["cls"], 0)).abs().max()) <= 1e-5
+    assert torch.allclose(out["reg"], torch.cat(want["reg"], 0), rtol=1e-6, atol=2e-4)
+    for i in range(len(scenes)):     # and against the reference itself
+        a = sum(sizes[:i])
+        assert float(np.abs(out["cls"][a:a + sizes[i]].cpu().numpy() - golden["net/cls/%d" % i]).max()) <= 2e-4
