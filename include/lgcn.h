@@ -210,6 +210,10 @@ typedef struct {
  */
 int lgcn_agg_mlp(const lgcn_agg_mlp_t *p_host, void *stream);
 
+/* Two independent row blocks (e.g. Att's per-target U and per-context V, lanegcn.py:696-699) in ONE launch when both
+ * are split-precision problems without CSR relations; otherwise the same as two lgcn_agg_mlp calls. */
+int lgcn_agg_mlp_pair(const lgcn_agg_mlp_t *a_host, const lgcn_agg_mlp_t *b_host, void *stream);
+
 /*
  * MapNet input stage, lanegcn.py:324-327:
  *   out = ReLU( GN_a(W_a2 ReLU(W_a1 ctr + b_a1)) + GN_s(W_s2 ReLU(W_s1 seg + b_s1)) )

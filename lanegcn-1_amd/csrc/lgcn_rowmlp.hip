@@ -489,9 +489,7 @@ int lgcn_pack_weight_t(const float *W, int ld, int mma, void *out, void *stream)
     return launch_status();
 }
 
-int lgcn_agg_mlp(const lgcn_agg_mlp_t *ph, void *stream) {
-    LGCN_CHECK_PTR(ph);
-    const lgcn_agg_mlp_t &p = *ph;
+static int validate_agg(const lgcn_agg_mlp_t &p, bool *need_col_out) {
     if (p.n_rows < 0 || p.n_rel < 1 || p.n_rel > LGCN_MAX_REL || !valid_mma(p.mma)) return LGCN_EINVAL;
     if (p.n_rows == 0) return LGCN_OK;
     if (p.n_rows > 0x7fffffff) return LGCN_ESHAPE;
@@ -521,6 +519,18 @@ int lgcn_agg_mlp(const lgcn_agg_mlp_t *ph, void *stream) {
     if (p.flags & LGCN_F_RES) { LGCN_CHECK_PTR(p.res); LGCN_CHECK_ALIGN16(p.res); }
     if (p.w4) { LGCN_CHECK_PTR(p.x4_a); LGCN_CHECK_PTR(p.x4_b); LGCN_CHECK_PTR(p.x4_c); LGCN_CHECK_ALIGN16(p.w4); }
     if (p.out_pre) LGCN_CHECK_ALIGN16(p.out_pre);
+    if (p.out_mid) LGCN_CHECK_ALIGN16(p.out_mid);
+    if (p.out_pre2) LGCN_CHECK_ALIGN16(p.out_pre2);
+    *need_col_out = need_col;
+    return LGCN_OK;
+}
+
+int lgcn_agg_mlp(const lgcn_agg_mlp_t *ph, void *stream) {
+    LGCN_CHECK_PTR(ph);
+    const lgcn_agg_mlp_t &p = *ph;
+    bool need_col = false;
+    const int rc = validate_agg(p, &need_col);
+    if (rc != LGCN_OK || p.n_rows == 0) return rc;
     if (p.mma != LGCN_MMA_F32) return agg_mlp_bf(p, need_col, (hipStream_t)stream);
     const int n_tiles = (int)((p.n_rows + kTM32 - 1) / kTM32);
     if (need_col)
@@ -528,6 +538,21 @@ int lgcn_agg_mlp(const lgcn_agg_mlp_t *ph, void *stream) {
     else
         hipLaunchKernelGGL((k_agg_mlp<0>), dim3(n_tiles), dim3(512), 0, (hipStream_t)stream, p, n_tiles);
     return launch_status();
+}
+
+int lgcn_agg_mlp_pair(const lgcn_agg_mlp_t *a, const lgcn_agg_mlp_t *b, void *stream) {
+    LGCN_CHECK_PTR(a); LGCN_CHECK_PTR(b);
+    bool ca = false, cb = false;
+    int rc = validate_agg(*a, &ca);
+    if (rc != LGCN_OK) return rc;
+    rc = validate_agg(*b, &cb);
+    if (rc != LGCN_OK) return rc;
+    // one launch only for two non-empty split-precision problems without CSR relations in the same mode
+    if (a->n_rows > 0 && b->n_rows > 0 && a->mma == b->mma && a->mma != LGCN_MMA_F32 && !ca && !cb &&
+        a->tile_rb == 0 && b->tile_rb == 0)
+        return agg_mlp_pair_bf(*a, *b, (hipStream_t)stream);
+    rc = lgcn_agg_mlp(a, stream);
+    return rc != LGCN_OK ? rc : lgcn_agg_mlp(b, stream);
 }
 
 int lgcn_mapnet_input(const float *ctrs, const float *feats, int64_t n_rows, const float *wa1, const float *ba1,

@@ -353,11 +353,10 @@ __device__ __forceinline__ void gather_finish(GReg<RB> &g, uint16_t *__restrict_
 }
 
 template <int RB, int F, int KIND, bool DEEP>
-__global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
+__device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, int bid, unsigned char *smem) {
     using TL = Tile<RB, F>;
     using IX = TileIdx<RB>;
     constexpr int ROWS = TL::ROWS;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[TL::SMEM + 128 + IX::INTS * 4];
     uint16_t *buf0 = reinterpret_cast<uint16_t *>(smem);
     uint16_t *buf1 = reinterpret_cast<uint16_t *>(smem + TL::ABUF_BYTES);
     float *T = reinterpret_cast<float *>(smem);                                 // aliases the A buffers
@@ -366,14 +365,14 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
     const IX ix(reinterpret_cast<int *>(smem + TL::SMEM + 128));
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile = xcd_chunk_remap(blockIdx.x, n_tiles);
+    const int tile = xcd_chunk_remap(bid, n_tiles);
     const int64_t row0 = (int64_t)tile * ROWS;
     const int64_t n_sub = (p.n_rows + 15) >> 4;
 #ifdef LGCN_STAMPS
     // wave 0 (MFMA role) -> slots 0..63, wave 4 (gather role) -> slots 64..127 of this block's 128-slot record
     unsigned long long *sbuf = nullptr;
     if (KIND == 1 && p.out_pre && (wave == 0 || wave == 4))
-        sbuf = reinterpret_cast<unsigned long long *>(p.out_pre) + (int64_t)blockIdx.x * 128 + (wave == 4 ? 64 : 0);
+        sbuf = reinterpret_cast<unsigned long long *>(p.out_pre) + (int64_t)bid * 128 + (wave == 4 ? 64 : 0);
     LGCN_STAMP(0);
 #endif
     const int nrc = p.n_rel_csr;
@@ -557,6 +556,22 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
         }
     }
     LGCN_STAMP(46);
+}
+
+template <int RB, int F, int KIND, bool DEEP>
+__global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4];
+    agg_body<RB, F, KIND, DEEP>(p, n_tiles, blockIdx.x, smem);
+}
+
+// Two independent row blocks in one launch (Att's U and V: same shape of work, different inputs): blocks
+// [0, tiles_a) run problem a, the rest problem b.  One kernel boundary and one launch latency instead of two.
+template <int RB, int F>
+__global__ __launch_bounds__(512) void k_agg_mlp_bf2(const lgcn_agg_mlp_t pa, const lgcn_agg_mlp_t pb, int tiles_a,
+                                                     int tiles_b) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4];
+    if ((int)blockIdx.x < tiles_a) agg_body<RB, F, 0, false>(pa, tiles_a, blockIdx.x, smem);
+    else agg_body<RB, F, 0, false>(pb, tiles_b, blockIdx.x - tiles_a, smem);
 }
 
 // ------------------------------------------------------- shared pieces -----
@@ -776,6 +791,23 @@ int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st) {
         case 1: if (deep) launch_agg<1, true>(p, rb, lane_conv, st); else launch_agg<1, false>(p, rb, lane_conv, st); break;
         default: if (deep) launch_agg<2, true>(p, rb, lane_conv, st); else launch_agg<2, false>(p, rb, lane_conv, st); break;
     }
+    return launch_status();
+}
+
+int agg_mlp_pair_bf(const lgcn_agg_mlp_t &a, const lgcn_agg_mlp_t &b, hipStream_t st) {
+    // one tile height for both problems: the one picked for the larger of the two
+    const int rb = pick_rb(a.n_rows > b.n_rows ? a.n_rows : b.n_rows, 1);
+    const int rows = 16 * rb;
+    const int ta = (int)((a.n_rows + rows - 1) / rows), tb = (int)((b.n_rows + rows - 1) / rows);
+#define LGCN_AGG2(RB_, F_) hipLaunchKernelGGL((k_agg_mlp_bf2<RB_, F_>), dim3(ta + tb), dim3(512), 0, st, a, b, ta, tb)
+#define LGCN_AGG2_RB(F_) switch (rb) { case 1: LGCN_AGG2(1, F_); break; case 2: LGCN_AGG2(2, F_); break; case 3: LGCN_AGG2(3, F_); break; default: LGCN_AGG2(4, F_); }
+    switch (fmt_of(a.mma)) {
+        case 0: LGCN_AGG2_RB(0); break;
+        case 1: LGCN_AGG2_RB(1); break;
+        default: LGCN_AGG2_RB(2); break;
+    }
+#undef LGCN_AGG2_RB
+#undef LGCN_AGG2
     return launch_status();
 }
 

@@ -372,21 +372,23 @@ class Att(nn.Module):
         T = agts.shape[0]
         lin = self.linear
         c0 = self.ctx[0]
-        # row-wise Linears commute with the gathers agts[hi] / ctx[wi]: evaluate them per node
-        wv = ops.packed(c0.linear.weight, 256, 128)
+        # row-wise Linears commute with the gathers agts[hi] / ctx[wi]: evaluate them per node.  U (per target:
+        # query -> GN -> ReLU -> ctx.0[:,128:256]) and V (per context row: ctx.0[:,256:384]) are independent:
+        # one dual-problem launch
+        u_kw = dict(n_rows=T, rels=[ops.RelSpec(agts, ops.packed(self.query.linear.weight))],
+                    flags=L.F_GN1 | L.F_RELU1 | L.F_GEMM2, gn1=_gn(self.query.norm),
+                    wp2=ops.packed(c0.linear.weight, 128, 128), eps=self.query.norm.eps)
+        v_kw = dict(n_rows=ctx.shape[0], rels=[ops.RelSpec(ctx, ops.packed(c0.linear.weight, 256, 128))], flags=0)
         if side is not None:
             main = torch.cuda.current_stream()
             V = torch.empty((ctx.shape[0], ops.C_FEAT), dtype=torch.float32, device=ctx.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                ops.agg_mlp(ctx.shape[0], [ops.RelSpec(ctx, wv)], 0, out=V)
-        U = ops.agg_mlp(T, [ops.RelSpec(agts, ops.packed(self.query.linear.weight))],
-                        L.F_GN1 | L.F_RELU1 | L.F_GEMM2, gn1=_gn(self.query.norm),
-                        wp2=ops.packed(c0.linear.weight, 128, 128), eps=self.query.norm.eps)
-        if side is not None:
+                ops.agg_mlp(out=V, **v_kw)
+            U = ops.agg_mlp(**u_kw)
             main.wait_stream(side)
         else:
-            V = ops.agg_mlp(ctx.shape[0], [ops.RelSpec(ctx, wv)], 0)
+            U, V = ops.agg_mlp_pair(u_kw, v_kw)
         m = ops.att_pairs(ps, self.dist[0].weight, self.dist[0].bias, ops.packed(self.dist[2].linear.weight),
                           _gn(self.dist[2].norm), ops.packed(c0.linear.weight, 0, 128), U, V, _gn(c0.norm),
                           eps=c0.norm.eps)

@@ -314,11 +314,10 @@ class RelSpec:
     ridx: int = 0
 
 
-def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, col=None, n_rel_csr=0,
-            gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, out_mid=None, out_pre2=None, eps=EPS, tag=None,
-            tile_rb=0):
-    """Fused aggregate -> GEMM -> GN -> ReLU -> GEMM -> GN -> +res -> ReLU row block (lgcn_agg_mlp)."""
-    lib = L.load()
+def _agg_params(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, col=None, n_rel_csr=0,
+                gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, out_mid=None,
+                out_pre2=None, eps=EPS, tile_rb=0):
+    """Fill one lgcn_agg_mlp_t.  Returns (struct, tensors to keep alive until the launch is enqueued, out)."""
     if not rels or len(rels) > L.MAX_REL:
         raise L.LgcnError("agg_mlp: 1..%d relations" % L.MAX_REL)
     dev = rels[0].src.device
@@ -328,9 +327,8 @@ def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, co
     keep = []
     for i, r in enumerate(rels):
         s = _dev(r.src, torch.float32, "rel.src")
-        keep.append(s)
+        keep += [s, r.wp]
         p.rel[i].src, p.rel[i].wp, p.rel[i].mode, p.rel[i].ridx = s.data_ptr(), r.wp.data_ptr(), r.mode, r.ridx
-        keep.append(r.wp)
     p.rowptr = 0 if rowptr is None else rowptr.data_ptr()
     p.col = 0 if col is None else col.data_ptr()
     if w4 is not None:
@@ -346,6 +344,7 @@ def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, co
         p.gn2_g, p.gn2_b = gn2[0].data_ptr(), gn2[1].data_ptr()
     if res is not None:
         res = _dev(res, torch.float32, "res")
+        keep.append(res)
         p.res = res.data_ptr()
     if out is None:
         out = torch.empty((n_rows, C_FEAT), dtype=torch.float32, device=dev)
@@ -353,9 +352,28 @@ def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, co
     p.out_pre = 0 if out_pre is None else out_pre.data_ptr()
     p.out_mid = 0 if out_mid is None else out_mid.data_ptr()
     p.out_pre2 = 0 if out_pre2 is None else out_pre2.data_ptr()
+    return p, keep, out
+
+
+def agg_mlp(n_rows: int, rels: Sequence[RelSpec], flags: int, *, tag=None, **kw):
+    """Fused aggregate -> GEMM -> GN -> ReLU -> GEMM -> GN -> +res -> ReLU row block (lgcn_agg_mlp).
+    Keywords: rowptr, col, n_rel_csr, gn1, wp2, gn2, res, x4, w4, out, out_pre, out_mid, out_pre2, eps, tile_rb."""
+    lib = L.load()
+    p, keep, out = _agg_params(n_rows, rels, flags, **kw)
     with _Timed(tag):
         L.check(lib.lgcn_agg_mlp(C.byref(p), _stream()), "lgcn_agg_mlp")
     return out
+
+
+def agg_mlp_pair(a: dict, b: dict, tag=None):
+    """Two independent row blocks in one launch (lgcn_agg_mlp_pair).  a, b: keyword dicts of agg_mlp
+    (n_rows, rels, flags, ...).  Returns (out_a, out_b)."""
+    lib = L.load()
+    pa, ka, oa = _agg_params(**a)
+    pb, kb, ob = _agg_params(**b)
+    with _Timed(tag):
+        L.check(lib.lgcn_agg_mlp_pair(C.byref(pa), C.byref(pb), _stream()), "lgcn_agg_mlp_pair")
+    return oa, ob
 
 
 def mapnet_input(ctrs, feats, wa1, ba1, wpa2, gn_a, ws1, bs1, wps2, gn_s, eps=EPS):
