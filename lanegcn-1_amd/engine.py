@@ -41,8 +41,10 @@ class FlatBatch:
     n_edges: List[int]
 
 
-def collate_flat(scenes: List[Dict], device=None) -> FlatBatch:
-    """Host collate of scene dicts (numpy or CPU torch leaves) into a FlatBatch on `device`."""
+def collate_flat(scenes: List[Dict], device=None, pin: bool = False) -> FlatBatch:
+    """Host collate of scene dicts (numpy or CPU torch leaves) into a FlatBatch on `device`.
+    pin: stage through pinned memory (asynchronous copies; allocating pinned buffers per call costs more than
+    it saves for these ~2 MB batches, so a loader that wants it should reuse its own staging buffers)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
 
     def npy(x):
@@ -90,7 +92,9 @@ def collate_flat(scenes: List[Dict], device=None) -> FlatBatch:
 
     def up(a, dtype=None):
         t = torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype)))
-        return t if dev.type == "cpu" else t.pin_memory().to(dev, non_blocking=True)
+        if dev.type == "cpu":
+            return t
+        return t.pin_memory().to(dev, non_blocking=True) if pin else t.to(dev)
 
     cat = lambda key, src: np.concatenate([npy(s[key]) for s in src], 0)
     return FlatBatch(
@@ -183,6 +187,7 @@ class HotPathEngine:
         if stages:
             out["a2a"] = act
         out["nodes"], out["actors"] = feat, act
+        out["n_pairs"] = [p.n_pairs for p in pairs]
         return out
 
     def capture(self, fb: FlatBatch, actors: torch.Tensor, warmup: int = 2, **fwd_kw):
@@ -223,12 +228,13 @@ class FullNetEngine:
 
     @torch.no_grad()
     def forward(self, fb: FlatBatch, actor_feats: torch.Tensor, rot: torch.Tensor, orig: torch.Tensor,
-                sizes: List[int]) -> Dict[str, torch.Tensor]:
+                sizes: List[int], return_pairs: bool = False) -> Dict[str, torch.Tensor]:
         """Returns {"cls": [A,6], "reg": [A,6,30,2]} for all actors of the batch (scene i = rows
         sum(sizes[:i]) .. sum(sizes[:i+1])), reg already in world coordinates."""
         net = self.net
         actors = net.actor_net(actor_feats)
-        actors = self.hot.forward(fb, actors)["actors"]
+        hot = self.hot.forward(fb, actors)
+        actors = hot["actors"]
         idcs, ctrs, st = [], [], 0
         for n in sizes:
             idcs.append(slice(st, st + n))
@@ -238,7 +244,10 @@ class FullNetEngine:
         reg = torch.cat(out["reg"], 0)
         cls = torch.cat(out["cls"], 0)
         reg = torch.einsum("amtk,akj->amtj", reg, rot) + orig.view(-1, 1, 1, 2)
-        return {"cls": cls, "reg": reg}
+        res = {"cls": cls, "reg": reg}
+        if return_pairs:
+            res["n_pairs"] = hot["n_pairs"]     # device counts of the three pair sets (A2M, M2A, A2A)
+        return res
 
     def capture(self, fb, actor_feats, rot, orig, sizes, warmup: int = 3):
         side = torch.cuda.Stream()

@@ -582,6 +582,8 @@ class Net(nn.Module):
         self.pred_net = PredNet(config)
 
     def forward(self, data: Dict) -> Dict[str, List[Tensor]]:
+        if not ops.wants_grad(*self.parameters()) and len(data["feats"]) > 0 and sum(len(x) for x in data["ctrs"]) > 0:
+            return self._forward_inference(data)
         actors, actor_idcs = actor_gather(gpu(data["feats"]))
         actor_ctrs = gpu(data["ctrs"])
         actors = self.actor_net(actors)
@@ -598,6 +600,45 @@ class Net(nn.Module):
         for i in range(len(out["reg"])):        # back to world coordinates (:147-150)
             out["reg"][i] = torch.matmul(out["reg"][i], rot[i]) + orig[i].view(1, 1, 1, -1)
         return out
+
+    def _forward_inference(self, data: Dict) -> Dict[str, List[Tensor]]:
+        """No-grad fast path of forward(): the batch is collated flat on the host (one H2D per array) and run
+        through engine.FullNetEngine -- same arithmetic and same outputs as the module path, without its
+        per-scene tensor ops.  Error behaviour is kept: KeyError when pre[5] / suc[5] is empty
+        (lanegcn.py:312-322) and, while Att.strict, RuntimeError when a fusion block has no pair (:688)."""
+        from .engine import FullNetEngine, collate_flat
+        eng = self.__dict__.get("_engine")
+        if eng is None:
+            eng = FullNetEngine(self)
+            self.__dict__["_engine"] = eng
+        n = len(data["feats"])
+        scenes = [{k: data[k][i] for k in ("feats", "ctrs", "rot", "orig", "graph")} for i in range(n)]
+        cpu = lambda t: t.cpu() if torch.is_tensor(t) and t.is_cuda else t
+        scenes = [{"feats": cpu(s["feats"]), "ctrs": cpu(s["ctrs"]), "rot": cpu(s["rot"]), "orig": cpu(s["orig"]),
+                   "graph": _tree_cpu(s["graph"])} for s in scenes]
+        fb = collate_flat(scenes)
+        ns = fb.num_scales
+        if fb.n_nodes == 0 or fb.n_edges[2 * ns - 2] == 0 or fb.n_edges[2 * ns - 1] == 0:
+            raise KeyError("node_idcs")
+        feats, rot, orig = eng.actor_inputs(scenes)
+        sizes = [len(s["ctrs"]) for s in scenes]
+        out = eng.forward(fb, feats, rot, orig, sizes, return_pairs=Att.strict)
+        if Att.strict and any(int(c) == 0 for c in torch.stack(out["n_pairs"]).flatten().tolist()):
+            raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
+        cls, reg, st = [], [], 0
+        for a in sizes:
+            cls.append(out["cls"][st:st + a])
+            reg.append(out["reg"][st:st + a])
+            st += a
+        return {"cls": cls, "reg": reg}
+
+
+def _tree_cpu(x):
+    if isinstance(x, dict):
+        return {k: _tree_cpu(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_tree_cpu(v) for v in x]
+    return x.cpu() if torch.is_tensor(x) and x.is_cuda else x
 
 
 class PredLoss(nn.Module):

@@ -22,7 +22,6 @@ def main():
     phase = sys.argv[1] if len(sys.argv) > 1 else "eager"      # eager | graph1 | graph4  (one phase per process)
     torch.manual_seed(0)
     net = M.Net(M.config).cuda().eval()
-    M.Att.strict = False
     res = {}
     scenes = gen.synth_batch("S2", seed=3)
     batch = gen.collate_fn(scenes)
