@@ -9,8 +9,8 @@ kernels on transposed plans / transposed weights plus three backward kernels:
 Only the K = 2 / K = 4 input Linears (nn.Linear(2,128) of the stems, the 4 meta columns) stay on stock
 ATen ops in the training path: they are [N,2]-shaped, not 128-d contractions.
 """
-from dataclasses import dataclass, field
-from typing import List, Optional, Tuple
+from dataclasses import dataclass
+from typing import List, Optional
 
 import torch
 from torch.autograd import Function
@@ -46,7 +46,6 @@ class BlockSpec:
     seg_ids: Optional[torch.Tensor] = None     # RANGE relation: segment id of every source row (int32)
     n_seg_rows: Optional[torch.Tensor] = None  # device count of valid source rows (int32 [1])
     tag: Optional[str] = None
-    n_src_rows: List[int] = field(default_factory=list)
 
 
 def _fwd_rels(spec: BlockSpec, srcs, weights):

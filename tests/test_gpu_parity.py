@@ -424,3 +424,28 @@ def test_full_net_engine_matches_net_forward(golden, ref_state_names, hip):
     for i in range(len(scenes)):     # and against the reference itself
         a = sum(sizes[:i])
         assert float(np.abs(out["cls"][a:a + sizes[i]].cpu().numpy() - golden["net/cls/%d" % i]).max()) <= 2e-4
+
+
+def test_engine_at_twice_the_baseline_batch_vs_oracle(hip, ref_state_names):
+    """64 scenes (20,736 nodes, 3,200 actors, ~215 k pairs) through the flat engine vs the oracle: guards the
+    index arithmetic (offsets, caps, scans over several blocks) beyond the BASELINE size."""
+    M, ops = hip
+    if ops.get_mma() != "f16x2":
+        pytest.skip("one mode is enough for the scale check")
+    from lanegcn_amd import data as gen
+    from lanegcn_amd.engine import HotPathEngine, collate_flat
+    sd = O.seeded_state(ref_state_names, 13)
+    mods = make_modules(M, sd)
+    scenes_np = gen.synth_batch("S2", seed=21, n_scenes=64)
+    scenes = [to_torch_scene(s) for s in scenes_np]
+    actors = torch.from_numpy(np.random.default_rng(5).normal(0, 1, (3200, 128)).astype(np.float32)).relu()
+    eng = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"])
+    out = eng.forward(collate_flat(scenes_np), actors.cuda(), stages=True)
+    torch.cuda.synchronize()
+    want = O.hot_path(O.graph_gather([s["graph"] for s in scenes]), actors, [s["ctrs"] for s in scenes], sd)
+    for k in ("map_net", "a2m", "m2m", "m2a", "a2a"):
+        assert float((out[k].cpu() - want[k]).abs().max()) <= FTOL, k
+    counts = [int(c) for c in torch.stack(out["n_pairs"]).flatten().tolist()]
+    for got, (a, c, th) in zip(counts, ((0, 1, 7.0), (1, 0, 6.0), (1, 1, 100.0))):
+        ctr = [[s["graph"]["ctrs"] for s in scenes], [s["ctrs"] for s in scenes]]
+        assert got == len(O.pair_search(ctr[a], ctr[c], th)[0])
