@@ -82,3 +82,29 @@ def test_pair_search_oracle_modes():
     hi_f, wi_f = O.pair_search(a, c, 1.0, legacy=False)
     assert hi_l.tolist() == [0, 0, 1, 1, 2, 2, 3, 4, 5, 6] and wi_l.tolist() == [0, 1, 0, 1, 0, 1, 2, 2, 2, 2]
     assert hi_f.tolist() == [0, 0, 1, 1, 2, 2, 5, 6, 7, 8] and wi_f.tolist() == [0, 1, 0, 1, 0, 1, 7, 7, 7, 7]
+
+
+def test_flat_scene_file_roundtrip(gen, tmp_path):
+    """flatfile.write_scenes / FlatSceneFile.batch (row f2) cut the same FlatBatch as collate_flat does from the
+    scene dicts, for an arbitrary subset and order of scenes, without pickles."""
+    from lanegcn_amd.engine import FullNetEngine, collate_flat
+    from lanegcn_amd.flatfile import FlatSceneFile, write_scenes
+    rng = np.random.default_rng(8)
+    scenes = [gen.synth_scene(rng, [4, 5], 6), gen.synth_scene(rng, [6], 3), gen.synth_scene(rng, [4, 4, 4], 9),
+              gen.synth_scene(rng, [5], 2)]
+    scenes[1]["graph"]["left"] = {"u": np.zeros(0, np.int64), "v": np.zeros(0, np.int64)}
+    path = str(tmp_path / "split.npz")
+    write_scenes(path, scenes)
+    store = FlatSceneFile(path)
+    assert len(store) == 4
+    pick = [2, 0, 3]
+    fb, ex = store.batch(pick, device="cpu")
+    want = collate_flat([scenes[i] for i in pick], device="cpu")
+    for name in ("n_scenes", "n_nodes", "n_actors", "num_scales", "rel_slices", "cap_a2m", "cap_a2a", "n_edges"):
+        assert getattr(fb, name) == getattr(want, name), name
+    for name in ("node_ctrs", "node_feats", "turn", "control", "intersect", "actor_ctrs", "node_off", "actor_off",
+                 "idx_local", "seg_off", "seg_base"):
+        assert torch.equal(getattr(fb, name), getattr(want, name)), name
+    feats, rot, orig = FullNetEngine.actor_inputs([scenes[i] for i in pick], device="cpu")
+    assert torch.equal(ex["actor_feats"], feats) and torch.equal(ex["rot"], rot) and torch.equal(ex["orig"], orig)
+    assert ex["sizes"] == [9, 6, 2] and ex["gt_preds"].shape == (17, 30, 2) and ex["has_preds"].dtype == torch.bool
