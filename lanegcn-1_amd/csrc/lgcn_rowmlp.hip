@@ -509,6 +509,10 @@ static int validate_agg(const lgcn_agg_mlp_t &p, bool *need_col_out) {
     }
     if (need_rowptr) LGCN_CHECK_PTR(p.rowptr);
     if (need_col) LGCN_CHECK_PTR(p.col);
+    if (need_col) {   // one rowptr per launch: a CSR plan and a RANGE prefix cannot be mixed
+        for (int r = 0; r < p.n_rel; ++r)
+            if (p.rel[r].mode == LGCN_REL_RANGE) return LGCN_EINVAL;
+    }
     if (p.flags & LGCN_F_GN1) { LGCN_CHECK_PTR(p.gn1_g); LGCN_CHECK_PTR(p.gn1_b); LGCN_CHECK_ALIGN16(p.gn1_g); LGCN_CHECK_ALIGN16(p.gn1_b); }
     if (p.flags & LGCN_F_GEMM2) { LGCN_CHECK_PTR(p.wp2); LGCN_CHECK_ALIGN16(p.wp2); }
     if (p.flags & LGCN_F_GN2) {

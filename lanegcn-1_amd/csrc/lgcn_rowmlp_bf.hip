@@ -264,92 +264,112 @@ template <int RB>
 struct TileIdx {
     static constexpr int RP = LGCN_MAX_REL * 16 + 4;   // ints per sub-tile chunk (<= 16*16+1)
     static constexpr int COLCAP = 64 * 16 * RB;        // col entries kept in LDS (fallback: global)
-    static constexpr int INTS = RB * RP + COLCAP + 16 * RB + 4 + 2 * RB + 4;
+    static constexpr int INTS = RB * RP + COLCAP + 16 * RB + 4;
     int *rp;      // [RB][RP]
     int *col;     // [COLCAP]
     int *rng;     // [16*RB + 1]
-    int *c0;      // [RB] first col entry of the sub-tile (global index)
-    int *lo;      // [RB] offset of the sub-tile's entries in `col`;  lo[RB] (stored at c0[-1]..) unused
-    int *flag;    // [0] = 1 when col[] holds the tile's entries
-    __device__ explicit TileIdx(int *base) {
-        rp = base; col = rp + RB * RP; rng = col + COLCAP; c0 = rng + 16 * RB + 4; lo = c0 + RB; flag = lo + RB;
-    }
+    __device__ explicit TileIdx(int *base) { rp = base; col = rp + RB * RP; rng = col + COLCAP; }
 };
 
-// A gather is split in two so that two relations can be in flight per gather wave:
-//   gather_issue : row bounds from LDS, then the FIRST source row of each of the wave's destination rows
-//                  as unconditional loads (index clamped to row 0 when a row has no source), so the
-//                  compiler can count them and a later finish of the OTHER register set does not drain them;
-//   gather_finish: remaining sources (rows with > 1 edge), bf16 split, LDS planes.
-template <int RB>
-struct GReg {
-    static constexpr int IT = 2 * RB;   // 8 destination rows per sweep (one half-wave per row)
-    float4 s[IT];
-    int b[IT], e[IT], cadj[IT];
-};
+// One relation's A operand: row n of the tile = sum of the source rows of n under this relation, split into
+// the format's planes.  One half-wave per destination row (32 lanes x 16 B = one 512-B source row), 8 rows per
+// sweep over the 4 gather waves, 2 RB sweeps.  All first-edge loads of the sweeps are issued before any is
+// used, and the second-edge loads of rows that have one go out with them, so a pass costs ONE global round
+// trip for in-degree <= 2 (the common case: lane graphs branch rarely) and one more per further edge of the
+// widest row, instead of one per sweep.  Edges are summed in index order, as the f32 kernel and the oracle do.
+// LDSCOL: the tile's col entries are in LDS (ix.col, local index = global index + cadj[sub-tile]).
+// MODE is a template parameter so that each mode's index reads and row loads are issued as straight-line batches.
+template <int RB, int F, int MODE, bool LDSCOL>
+__device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const lgcn_agg_mlp_t &p, int ri, int tile, int gt,
+                                            const TileIdx<RB> &ix, const int (&cadj)[RB]) {
+    constexpr int IT = 2 * RB;
+    constexpr int mode = MODE;
+    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(p.rel[ri].src);
+    const int ridx = p.rel[ri].ridx;     // wave-uniform
+    const int hw = gt >> 5, l = gt & 31;
+    int b[IT], e[IT];
+    if (mode == LGCN_REL_CSR) {
+        const int *rp = ix.rp + ridx * 16 + hw;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int o = (it >> 1) * TileIdx<RB>::RP + (it & 1) * 8;
+            const int adj = LDSCOL ? cadj[it >> 1] : 0;
+            b[it] = rp[o] + adj;
+            e[it] = rp[o + 1] + adj;
+        }
+    } else if (mode == LGCN_REL_RANGE) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) { b[it] = ix.rng[it * 8 + hw]; e[it] = ix.rng[it * 8 + hw + 1]; }
+    } else {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int64_t n = (int64_t)tile * (16 * RB) + it * 8 + hw;
+            const bool live = n < p.n_rows;
+            b[it] = live ? (int)n : 0;
+            e[it] = live ? (int)n + 1 : 0;
+        }
+    }
+    // source row of edge j (valid j only)
+    auto row_of = [&](int j) -> unsigned { return mode != LGCN_REL_CSR ? (unsigned)j : (unsigned)(LDSCOL ? ix.col[j] : p.col[j]); };
+    auto load = [&](unsigned r) -> float4 { return src[((uint64_t)r << 5) + l]; };
 
-template <int RB>
-__device__ __forceinline__ int gather_source(const lgcn_agg_mlp_t &p, const TileIdx<RB> &ix, int mode, bool lds_col,
-                                             int cadj, int j) {
-    if (mode != LGCN_REL_CSR) return j;
-    return lds_col ? ix.col[j + cadj] : p.col[j];
+    // by value: a ternary over two float4 lvalues selects ADDRESSES and sends the arrays to scratch
+    auto keep = [](bool c, float4 v) -> float4 { return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f); };
+    // edges j .. e-1 of one row added to acc in index order, four loads in flight
+    auto tail = [&](float4 acc, int j, int end) -> float4 {
+        for (; j + 3 < end; j += 4) {
+            const float4 y0 = load(row_of(j)), y1 = load(row_of(j + 1)), y2 = load(row_of(j + 2)), y3 = load(row_of(j + 3));
+            acc = f4add(f4add(f4add(f4add(acc, y0), y1), y2), y3);
+        }
+        for (; j < end; ++j) acc = f4add(acc, load(row_of(j)));
+        return acc;
+    };
+
+    float4 s[IT], x[IT];
+    bool more = false;
+#pragma unroll
+    for (int it = 0; it < IT; ++it) more = more | (b[it] + 1 < e[it]);
+    const bool any2 = __any(more);                       // some row of this wave has a second edge
+    unsigned r0[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        r0[it] = 0u;
+        if (b[it] < e[it]) r0[it] = row_of(b[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) s[it] = load(r0[it]);   // unconditional (row 0 when the row has no source)
+    if (any2) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            x[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b[it] + 1 < e[it]) x[it] = load(row_of(b[it] + 1));
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) s[it] = keep(b[it] < e[it], s[it]);
+    if (any2) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) s[it] = f4add(s[it], x[it]);
+        more = false;
+#pragma unroll
+        for (int it = 0; it < IT; ++it) more = more | (b[it] + 2 < e[it]);
+        if (__any(more)) {   // in-degree > 2 (rare in lane graphs, the rule for Att's RANGE sums)
+#pragma unroll
+            for (int it = 0; it < IT; ++it) s[it] = tail(s[it], b[it] + 2, e[it]);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) split_store<F>(Abuf, Tile<RB, F>::PLANE, it * 8 + hw, 4 * l, s[it]);
 }
 
-template <int RB>
-__device__ __forceinline__ void gather_issue(GReg<RB> &g, const lgcn_agg_mlp_t &p, int ri, int tile, int gt,
-                                             const TileIdx<RB> &ix) {
-    constexpr int IT = GReg<RB>::IT;
-    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(p.rel[ri].src);
-    const int mode = p.rel[ri].mode, ridx = p.rel[ri].ridx;
-    const int hw = gt >> 5, l = gt & 31;
-    const bool lds_col = ix.flag[0] != 0;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int row = it * 8 + hw;
-        const int64_t n = (int64_t)tile * (16 * RB) + row;
-        int b = 0, e = 0, cadj = 0;
-        if (n < p.n_rows) {
-            if (mode == LGCN_REL_CSR) {
-                const int rb = row >> 4;
-                b = ix.rp[rb * TileIdx<RB>::RP + ridx * 16 + (row & 15)];
-                e = ix.rp[rb * TileIdx<RB>::RP + ridx * 16 + (row & 15) + 1];
-                cadj = ix.lo[rb] - ix.c0[rb];      // global col index -> LDS col index
-            } else if (mode == LGCN_REL_RANGE) {
-                b = ix.rng[row]; e = ix.rng[row + 1];
-            } else {
-                b = (int)n; e = (int)n + 1;
-            }
-        }
-        g.b[it] = b; g.e[it] = e; g.cadj[it] = cadj;
-    }
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int idx = g.b[it] < g.e[it] ? gather_source<RB>(p, ix, mode, lds_col, g.cadj[it], g.b[it]) : 0;
-        g.s[it] = src[(int64_t)idx * 32 + l];
-    }
-}
-
-template <int RB, int F>
-__device__ __forceinline__ void gather_finish(GReg<RB> &g, uint16_t *__restrict__ Abuf, const lgcn_agg_mlp_t &p, int ri,
-                                              int gt, const TileIdx<RB> &ix) {
-    constexpr int IT = GReg<RB>::IT;
-    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(p.rel[ri].src);
-    const int mode = p.rel[ri].mode;
-    const int hw = gt >> 5, l = gt & 31;
-    const bool lds_col = ix.flag[0] != 0;
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        float4 s = g.b[it] < g.e[it] ? g.s[it] : make_float4(0.f, 0.f, 0.f, 0.f);
-        int j = g.b[it] + 1;
-        for (; j + 3 < g.e[it]; j += 4) {  // four loads in flight, summed in index order
-            float4 x[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) x[q] = src[(int64_t)gather_source<RB>(p, ix, mode, lds_col, g.cadj[it], j + q) * 32 + l];
-            s = f4add(f4add(f4add(f4add(s, x[0]), x[1]), x[2]), x[3]);
-        }
-        for (; j < g.e[it]; ++j) s = f4add(s, src[(int64_t)gather_source<RB>(p, ix, mode, lds_col, g.cadj[it], j) * 32 + l]);
-        split_store<F>(Abuf, Tile<RB, F>::PLANE, it * 8 + hw, 4 * l, s);
-    }
+// KIND 1 launches (LaneConv) hold IDENT and CSR relations, KIND 0 launches IDENT and RANGE ones.
+template <int RB, int F, int KIND, bool LDSCOL>
+__device__ __forceinline__ void gather_rel(uint16_t *__restrict__ Abuf, const lgcn_agg_mlp_t &p, int ri, int tile, int gt,
+                                           const TileIdx<RB> &ix, const int (&cadj)[RB]) {
+    const int mode = p.rel[ri].mode;     // wave-uniform
+    if (mode == LGCN_REL_IDENT) gather_mode<RB, F, LGCN_REL_IDENT, false>(Abuf, p, ri, tile, gt, ix, cadj);
+    else if (KIND == 1) gather_mode<RB, F, LGCN_REL_CSR, LDSCOL>(Abuf, p, ri, tile, gt, ix, cadj);
+    else gather_mode<RB, F, LGCN_REL_RANGE, false>(Abuf, p, ri, tile, gt, ix, cadj);
 }
 
 template <int RB, int F, int KIND, bool DEEP>
@@ -378,6 +398,23 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     const int nrc = p.n_rel_csr;
     const bool has_csr = KIND == 1, has_rng = KIND == 0 && p.rowptr != nullptr;
 
+    const int flags = p.flags;
+    const bool two = (flags & LGCN_F_GEMM2) != 0;
+    const int gt = tid - 256;
+    typename std::conditional<DEEP, BRing<F>, BPair<F>>::type bfrag;
+    int cadj[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) cadj[rb] = 0;
+
+    // ---- relation 0 = the row itself (LaneConv's ctr, every Linear): it is always active and needs no index,
+    // so the gather waves fetch it and the MFMA waves fetch its first weight fragments before the index
+    // slice is read; both round trips overlap the slice's
+    const bool early = p.rel[0].mode == LGCN_REL_IDENT;
+    if (early) {
+        if (wave >= 4) gather_mode<RB, F, LGCN_REL_IDENT, false>(buf0, p, 0, tile, gt, ix, cadj);
+        else ring_prime<F>(bfrag, reinterpret_cast<const uint4 *>(p.rel[0].wp), wave, lane);
+    }
+
     // ---- index slice -> LDS
     if (has_csr) {
         const int len = nrc * 16 + 1;
@@ -393,28 +430,23 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
         }
     }
     __syncthreads();
+    bool lds_col = false;
     if (has_csr) {
         int lo = 0;
-        bool fits = true;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {     // every thread computes the same (uniform) layout
             const int c0 = ix.rp[rb * IX::RP], c1 = ix.rp[rb * IX::RP + nrc * 16];
-            if (tid == 0) { ix.c0[rb] = c0; ix.lo[rb] = lo; }
+            cadj[rb] = __builtin_amdgcn_readfirstlane(lo - c0);   // global col index -> index into ix.col
             lo += c1 - c0;
         }
-        fits = lo <= IX::COLCAP;
-        if (tid == 0) ix.flag[0] = fits ? 1 : 0;
-        if (fits) {
-            lo = 0;
+        lds_col = __builtin_amdgcn_readfirstlane(lo) <= IX::COLCAP;
+        if (lds_col) {
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) {
                 const int c0 = ix.rp[rb * IX::RP], c1 = ix.rp[rb * IX::RP + nrc * 16];
-                for (int j = tid; j < c1 - c0; j += 512) ix.col[lo + j] = p.col[c0 + j];
-                lo += c1 - c0;
+                for (int j = tid; j < c1 - c0; j += 512) ix.col[c0 + cadj[rb] + j] = p.col[c0 + j];
             }
         }
-    } else if (tid == 0) {
-        ix.flag[0] = 0;
     }
     // ---- active relations of this tile (wave 7 so that it overlaps the col copy of the others)
     if (wave == 7) {
@@ -444,23 +476,21 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     // with relation i + 1 (one barrier per relation).  Latency is hidden across workgroups (keep the
     // VGPR count <= 128 so that two 8-wave workgroups fit a CU): a deeper per-wave register ring was
     // measured slower because it halves that occupancy.
-    const int flags = p.flags;
-    const bool two = (flags & LGCN_F_GEMM2) != 0;
-    const int gt = tid - 256;
     auto rel_at = [&](int i) { return __builtin_amdgcn_readfirstlane(act[i]); };
-    typename std::conditional<DEEP, BRing<F>, BPair<F>>::type bfrag;
-    if (wave >= 4) {
-        if (nact > 0) {
-            GReg<RB> g;
-            gather_issue<RB>(g, p, rel_at(0), tile, gt, ix);
-            gather_finish<RB, F>(g, buf0, p, rel_at(0), gt, ix);
+    auto gather = [&](uint16_t *dst, int ri) {
+        if (KIND == 1 && lds_col) gather_rel<RB, F, KIND, true>(dst, p, ri, tile, gt, ix, cadj);
+        else gather_rel<RB, F, KIND, false>(dst, p, ri, tile, gt, ix, cadj);
+    };
+    if (!early) {
+        if (wave >= 4) {
+            if (nact > 0) gather(buf0, rel_at(0));
+        } else {
+            const float *w0 = nact > 0 ? p.rel[rel_at(0)].wp : p.wp2;
+            if (w0 != nullptr) ring_prime<F>(bfrag, reinterpret_cast<const uint4 *>(w0), wave, lane);
         }
-    } else {
-        const float *w0 = nact > 0 ? p.rel[rel_at(0)].wp : p.wp2;
-        if (w0 != nullptr) ring_prime<F>(bfrag, reinterpret_cast<const uint4 *>(w0), wave, lane);
+        LGCN_STAMP(2);
+        __syncthreads();
     }
-    LGCN_STAMP(2);
-    __syncthreads();
     LGCN_STAMP(3);
 
     f32x4 acc[RB][2];
@@ -475,9 +505,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
                               reinterpret_cast<const uint4 *>(wn), bfrag, wave, lane, acc);
             }
         } else if (i + 1 < nact && !(flags & (1 << 8))) {   // ablation bit: skip the in-loop gathers
-            GReg<RB> g;
-            gather_issue<RB>(g, p, rel_at(i + 1), tile, gt, ix);
-            gather_finish<RB, F>(g, nxt, p, rel_at(i + 1), gt, ix);
+            gather(nxt, rel_at(i + 1));
         }
         LGCN_STAMP(4 + 2 * i);       // own work of pass i done
         __syncthreads();
@@ -558,8 +586,12 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     LGCN_STAMP(46);
 }
 
+// Tiles of <= 32 rows must keep two 8-wave workgroups per CU (4 waves per SIMD = 128 VGPRs): that co-residency
+// is what hides the weight-fragment latency; the register allocator is held to it.
+#define LGCN_WAVES_PER_SIMD(RB_, DEEP_) __attribute__((amdgpu_waves_per_eu((RB_) <= 2 && !(DEEP_) ? 4 : 2)))
+
 template <int RB, int F, int KIND, bool DEEP>
-__global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
+__global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, DEEP) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4];
     agg_body<RB, F, KIND, DEEP>(p, n_tiles, blockIdx.x, smem);
 }
@@ -567,7 +599,7 @@ __global__ __launch_bounds__(512) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int 
 // Two independent row blocks in one launch (Att's U and V: same shape of work, different inputs): blocks
 // [0, tiles_a) run problem a, the rest problem b.  One kernel boundary and one launch latency instead of two.
 template <int RB, int F>
-__global__ __launch_bounds__(512) void k_agg_mlp_bf2(const lgcn_agg_mlp_t pa, const lgcn_agg_mlp_t pb, int tiles_a,
+__global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, false) void k_agg_mlp_bf2(const lgcn_agg_mlp_t pa, const lgcn_agg_mlp_t pb, int tiles_a,
                                                      int tiles_b) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4];
     if ((int)blockIdx.x < tiles_a) agg_body<RB, F, 0, false>(pa, tiles_a, blockIdx.x, smem);

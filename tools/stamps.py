@@ -47,8 +47,8 @@ def main():
     print("rb=%d mma=%s tiles=%d  (cycles, median over workgroups; 100 MHz memtime? see total)" % (rb, ops.get_mma(), n_tiles))
     print("kernel span per WG (MFMA wave 0: stamp46 - stamp0): %.0f" % med(mf[:, 46]))
     print("  index preload + act (0->1): %.0f" % med(mf[:, 1]))
-    print("  MFMA: first weights (1->2) %.0f, wait first gather (2->3) %.0f" % (med(mf[:, 2] - mf[:, 1]), med(mf[:, 3] - mf[:, 2])))
-    print("  gather wave: first gather (1->2) %.0f" % med(ga[:, 2] - ga[:, 1]))
+    print("  index ready -> loop start (1->3; relation 0 is fetched before the index slice): MFMA %.0f, gather %.0f" % (
+        med(mf[:, 3] - mf[:, 1]), med(ga[:, 3] - ga[:, 1])))
     work_m = [med(mf[:, 4 + 2 * i] - mf[:, 3 + 2 * i]) for i in range(15)]
     wait_m = [med(mf[:, 5 + 2 * i] - mf[:, 4 + 2 * i]) for i in range(15)]
     work_g = [med(ga[:, 4 + 2 * i] - ga[:, 3 + 2 * i]) for i in range(15)]
