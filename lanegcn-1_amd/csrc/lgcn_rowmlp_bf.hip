@@ -201,6 +201,38 @@ __device__ __forceinline__ void gemm_pass(const uint16_t *__restrict__ A, const 
     kstep<RB, F>(arow, 3, r.b[3], acc);
 }
 
+// Second GEMM of a block (one pass over wp2).  On entry the ring holds K-step 0 (K-steps 0..2 for the deep
+// ring), prefetched by the last relation pass; gemm2_prefetch, called while the row phase runs on the other waves, adds the K-steps the
+// ring has room for, so that gemm2_pass starts with them landed.
+template <int F>
+__device__ __forceinline__ void gemm2_prefetch(BPair<F> &r, const uint4 *__restrict__ Bw, int wave, int lane) {
+    load_b<F>(r.b[1], Bw, wave, lane, 1);
+}
+template <int F>
+__device__ __forceinline__ void gemm2_prefetch(BRing<F> &r, const uint4 *__restrict__ Bw, int wave, int lane) {
+    load_b<F>(r.b[3], Bw, wave, lane, 3);   // K-steps 0..2 came with the last relation pass
+}
+template <int RB, int F>
+__device__ __forceinline__ void gemm2_pass(const uint16_t *__restrict__ A, const uint4 *__restrict__ Bw, BPair<F> &r,
+                                           int wave, int lane, f32x4 (&acc)[RB][2]) {
+    const uint16_t *arow = A + (lane & 15) * kLDB + 8 * (lane >> 4);
+    kstep<RB, F>(arow, 0, r.b[0], acc);
+    load_b<F>(r.b[0], Bw, wave, lane, 2);
+    kstep<RB, F>(arow, 1, r.b[1], acc);
+    load_b<F>(r.b[1], Bw, wave, lane, 3);
+    kstep<RB, F>(arow, 2, r.b[0], acc);
+    kstep<RB, F>(arow, 3, r.b[1], acc);
+}
+template <int RB, int F>
+__device__ __forceinline__ void gemm2_pass(const uint16_t *__restrict__ A, const uint4 *__restrict__, BRing<F> &r,
+                                           int wave, int lane, f32x4 (&acc)[RB][2]) {
+    const uint16_t *arow = A + (lane & 15) * kLDB + 8 * (lane >> 4);
+    kstep<RB, F>(arow, 0, r.b[0], acc);
+    kstep<RB, F>(arow, 1, r.b[1], acc);
+    kstep<RB, F>(arow, 2, r.b[2], acc);
+    kstep<RB, F>(arow, 3, r.b[3], acc);
+}
+
 // C/D layout of 16x16: col = lane & 15, row = 4 (lane >> 4) + reg
 template <int RB>
 __device__ __forceinline__ void acc_store(float *T, const f32x4 (&acc)[RB][2], int lane, int wave) {
@@ -279,14 +311,37 @@ struct TileIdx {
 // widest row, instead of one per sweep.  Edges are summed in index order, as the f32 kernel and the oracle do.
 // LDSCOL: the tile's col entries are in LDS (ix.col, local index = global index + cadj[sub-tile]).
 // MODE is a template parameter so that each mode's index reads and row loads are issued as straight-line batches.
-template <int RB, int F, int MODE, bool LDSCOL>
+//
+// Registers: a wave is either a gather wave or an MFMA wave for the whole kernel, but the allocator sees one
+// function, so what the gather holds would come on top of the accumulators and weight fragments that only
+// the MFMA waves use.  The gather therefore keeps its 2 RB row sums IN the accumulator variables (same
+// count: acc[RB][2]) and, where they fit, the second-edge rows in the spare weight-fragment set; both are
+// dead values on a gather wave.  This is what keeps 32-row tiles at 128 VGPRs (two workgroups per CU).
+template <int F, class Ring, int IT>
+struct XRows {   // second-edge rows: ring.b[1] when it has IT 16-B slots, a local array otherwise
+    static constexpr bool kAlias = IT <= 2 * Fmt<F>::NP;
+    Ring &ring;
+    f32x4 own[kAlias ? 1 : IT];
+    __device__ explicit XRows(Ring &r) : ring(r) {}
+    __device__ __forceinline__ void set(int i, f32x4 v) {
+        if constexpr (kAlias) ring.b[1].v[i >> 1][i & 1] = __builtin_bit_cast(uint4, v);
+        else own[i] = v;
+    }
+    __device__ __forceinline__ f32x4 get(int i) const {
+        if constexpr (kAlias) return __builtin_bit_cast(f32x4, ring.b[1].v[i >> 1][i & 1]);
+        else return own[i];
+    }
+};
+
+template <int RB, int F, int MODE, bool LDSCOL, class Ring>
 __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const lgcn_agg_mlp_t &p, int ri, int tile, int gt,
-                                            const TileIdx<RB> &ix, const int (&cadj)[RB]) {
+                                            const TileIdx<RB> &ix, const int (&cadj)[RB], f32x4 (&s)[RB][2], Ring &ring) {
     constexpr int IT = 2 * RB;
     constexpr int mode = MODE;
-    const float4 *__restrict__ src = reinterpret_cast<const float4 *>(p.rel[ri].src);
+    const f32x4 *__restrict__ src = reinterpret_cast<const f32x4 *>(p.rel[ri].src);
     const int ridx = p.rel[ri].ridx;     // wave-uniform
     const int hw = gt >> 5, l = gt & 31;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     int b[IT], e[IT];
     if (mode == LGCN_REL_CSR) {
         const int *rp = ix.rp + ridx * 16 + hw;
@@ -301,35 +356,36 @@ __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const l
 #pragma unroll
         for (int it = 0; it < IT; ++it) { b[it] = ix.rng[it * 8 + hw]; e[it] = ix.rng[it * 8 + hw + 1]; }
     } else {
+        // an IDENT gather is the same every pass; the opaque zero keeps its addressing out of the loop
+        // pre-header, where the hoisted values would hold registers for the whole kernel
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             const int64_t n = (int64_t)tile * (16 * RB) + it * 8 + hw;
             const bool live = n < p.n_rows;
-            b[it] = live ? (int)n : 0;
-            e[it] = live ? (int)n + 1 : 0;
+            b[it] = live ? (int)n + opq : 0;
+            e[it] = live ? (int)n + opq + 1 : 0;
         }
     }
     // source row of edge j (valid j only)
     auto row_of = [&](int j) -> unsigned { return mode != LGCN_REL_CSR ? (unsigned)j : (unsigned)(LDSCOL ? ix.col[j] : p.col[j]); };
-    auto load = [&](unsigned r) -> float4 { return src[((uint64_t)r << 5) + l]; };
-
-    // by value: a ternary over two float4 lvalues selects ADDRESSES and sends the arrays to scratch
-    auto keep = [](bool c, float4 v) -> float4 { return make_float4(c ? v.x : 0.f, c ? v.y : 0.f, c ? v.z : 0.f, c ? v.w : 0.f); };
+    auto load = [&](unsigned r) -> f32x4 { return src[((uint64_t)r << 5) + l]; };
     // edges j .. e-1 of one row added to acc in index order, four loads in flight
-    auto tail = [&](float4 acc, int j, int end) -> float4 {
+    auto tail = [&](f32x4 acc, int j, int end) -> f32x4 {
         for (; j + 3 < end; j += 4) {
-            const float4 y0 = load(row_of(j)), y1 = load(row_of(j + 1)), y2 = load(row_of(j + 2)), y3 = load(row_of(j + 3));
-            acc = f4add(f4add(f4add(f4add(acc, y0), y1), y2), y3);
+            const f32x4 y0 = load(row_of(j)), y1 = load(row_of(j + 1)), y2 = load(row_of(j + 2)), y3 = load(row_of(j + 3));
+            acc = (((acc + y0) + y1) + y2) + y3;
         }
-        for (; j < end; ++j) acc = f4add(acc, load(row_of(j)));
+        for (; j < end; ++j) acc = acc + load(row_of(j));
         return acc;
     };
 
-    float4 s[IT], x[IT];
+    XRows<F, Ring, IT> x(ring);
     bool more = false;
 #pragma unroll
     for (int it = 0; it < IT; ++it) more = more | (b[it] + 1 < e[it]);
-    const bool any2 = __any(more);                       // some row of this wave has a second edge
+    const bool any2 = MODE != LGCN_REL_IDENT && __any(more);   // some row of this wave has a second edge
     unsigned r0[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
@@ -337,39 +393,43 @@ __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const l
         if (b[it] < e[it]) r0[it] = row_of(b[it]);
     }
 #pragma unroll
-    for (int it = 0; it < IT; ++it) s[it] = load(r0[it]);   // unconditional (row 0 when the row has no source)
+    for (int it = 0; it < IT; ++it) s[it >> 1][it & 1] = load(r0[it]);   // unconditional (row 0 when the row has no source)
     if (any2) {
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
-            x[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b[it] + 1 < e[it]) x[it] = load(row_of(b[it] + 1));
+            f32x4 v = zero;
+            if (b[it] + 1 < e[it]) v = load(row_of(b[it] + 1));
+            x.set(it, v);
         }
     }
 #pragma unroll
-    for (int it = 0; it < IT; ++it) s[it] = keep(b[it] < e[it], s[it]);
+    for (int it = 0; it < IT; ++it) s[it >> 1][it & 1] = b[it] < e[it] ? s[it >> 1][it & 1] : zero;
     if (any2) {
 #pragma unroll
-        for (int it = 0; it < IT; ++it) s[it] = f4add(s[it], x[it]);
+        for (int it = 0; it < IT; ++it) s[it >> 1][it & 1] = s[it >> 1][it & 1] + x.get(it);
         more = false;
 #pragma unroll
         for (int it = 0; it < IT; ++it) more = more | (b[it] + 2 < e[it]);
         if (__any(more)) {   // in-degree > 2 (rare in lane graphs, the rule for Att's RANGE sums)
 #pragma unroll
-            for (int it = 0; it < IT; ++it) s[it] = tail(s[it], b[it] + 2, e[it]);
+            for (int it = 0; it < IT; ++it) s[it >> 1][it & 1] = tail(s[it >> 1][it & 1], b[it] + 2, e[it]);
         }
     }
 #pragma unroll
-    for (int it = 0; it < IT; ++it) split_store<F>(Abuf, Tile<RB, F>::PLANE, it * 8 + hw, 4 * l, s[it]);
+    for (int it = 0; it < IT; ++it) {
+        const f32x4 v = s[it >> 1][it & 1];
+        split_store<F>(Abuf, Tile<RB, F>::PLANE, it * 8 + hw, 4 * l, make_float4(v[0], v[1], v[2], v[3]));
+    }
 }
 
 // KIND 1 launches (LaneConv) hold IDENT and CSR relations, KIND 0 launches IDENT and RANGE ones.
-template <int RB, int F, int KIND, bool LDSCOL>
+template <int RB, int F, int KIND, bool LDSCOL, class Ring>
 __device__ __forceinline__ void gather_rel(uint16_t *__restrict__ Abuf, const lgcn_agg_mlp_t &p, int ri, int tile, int gt,
-                                           const TileIdx<RB> &ix, const int (&cadj)[RB]) {
+                                           const TileIdx<RB> &ix, const int (&cadj)[RB], f32x4 (&s)[RB][2], Ring &ring) {
     const int mode = p.rel[ri].mode;     // wave-uniform
-    if (mode == LGCN_REL_IDENT) gather_mode<RB, F, LGCN_REL_IDENT, false>(Abuf, p, ri, tile, gt, ix, cadj);
-    else if (KIND == 1) gather_mode<RB, F, LGCN_REL_CSR, LDSCOL>(Abuf, p, ri, tile, gt, ix, cadj);
-    else gather_mode<RB, F, LGCN_REL_RANGE, false>(Abuf, p, ri, tile, gt, ix, cadj);
+    if (mode == LGCN_REL_IDENT) gather_mode<RB, F, LGCN_REL_IDENT, false>(Abuf, p, ri, tile, gt, ix, cadj, s, ring);
+    else if (KIND == 1) gather_mode<RB, F, LGCN_REL_CSR, LDSCOL>(Abuf, p, ri, tile, gt, ix, cadj, s, ring);
+    else gather_mode<RB, F, LGCN_REL_RANGE, false>(Abuf, p, ri, tile, gt, ix, cadj, s, ring);
 }
 
 template <int RB, int F, int KIND, bool DEEP>
@@ -402,67 +462,83 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     const bool two = (flags & LGCN_F_GEMM2) != 0;
     const int gt = tid - 256;
     typename std::conditional<DEEP, BRing<F>, BPair<F>>::type bfrag;
+    f32x4 acc[RB][2];       // MFMA waves: accumulators; gather waves: the row sums of the relation in flight
     int cadj[RB];
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) cadj[rb] = 0;
 
-    // ---- relation 0 = the row itself (LaneConv's ctr, every Linear): it is always active and needs no index,
-    // so the gather waves fetch it and the MFMA waves fetch its first weight fragments before the index
-    // slice is read; both round trips overlap the slice's
-    const bool early = p.rel[0].mode == LGCN_REL_IDENT;
-    if (early) {
-        if (wave >= 4) gather_mode<RB, F, LGCN_REL_IDENT, false>(buf0, p, 0, tile, gt, ix, cadj);
-        else ring_prime<F>(bfrag, reinterpret_cast<const uint4 *>(p.rel[0].wp), wave, lane);
+    // ---- prologue, one barrier.  Order of issue: (1) the index words every wave needs from global memory
+    // (bounds of the tile's col entries, this thread's word of each rowptr chunk, wave 7: the activity words
+    // of its relation), (2) relation 0 when it is the row itself (LaneConv's ctr, every Linear: always
+    // active, needs no index): its rows on the gather waves, its first weight fragments on the MFMA waves,
+    // (3) the col entries, whose addresses depend on (1).  (1) and (2) share one round trip.
+    float *gnp = reinterpret_cast<float *>(smem + TL::SMEM + 128 + IX::INTS * 4);   // gn1 g|b, gn2 g|b
+    if (tid >= 128 && tid < 256) {
+        const int c = tid - 128;
+        if (flags & LGCN_F_GN1) { gnp[c] = p.gn1_g[c]; gnp[kC + c] = p.gn1_b[c]; }
+        if (flags & LGCN_F_GN2) { gnp[2 * kC + c] = p.gn2_g[c]; gnp[3 * kC + c] = p.gn2_b[c]; }
     }
-
-    // ---- index slice -> LDS
+    const int len = nrc * 16 + 1;     // <= 257 ints per sub-tile: one per thread
+    int c0[RB], c1[RB], rpv[RB], a0[RB], a1[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) c0[rb] = c1[rb] = rpv[rb] = a0[rb] = a1[rb] = 0;
     if (has_csr) {
-        const int len = nrc * 16 + 1;
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) {
             const int64_t sub = (int64_t)tile * RB + rb;
-            for (int j = tid; j < len; j += 512) ix.rp[rb * IX::RP + j] = sub < n_sub ? p.rowptr[sub * nrc * 16 + j] : 0;
+            const int32_t *chunk = p.rowptr + sub * nrc * 16;
+            if (sub < n_sub) {
+                c0[rb] = chunk[0];
+                c1[rb] = chunk[nrc * 16];
+                if (tid < len) rpv[rb] = chunk[tid];
+                if (wave == 7 && lane < p.n_rel && p.rel[lane].mode == LGCN_REL_CSR) {
+                    a0[rb] = chunk[p.rel[lane].ridx * 16];
+                    a1[rb] = chunk[p.rel[lane].ridx * 16 + 16];
+                }
+            }
         }
+    } else if (has_rng) {
+        if (wave == 7 && lane < p.n_rel && p.rel[lane].mode == LGCN_REL_RANGE) {
+            a0[0] = p.rowptr[row0 < p.n_rows ? row0 : p.n_rows];
+            a1[0] = p.rowptr[row0 + ROWS < p.n_rows ? row0 + ROWS : p.n_rows];
+        }
+    }
+    const bool early = p.rel[0].mode == LGCN_REL_IDENT;
+    if (early) {
+        if (wave >= 4) gather_mode<RB, F, LGCN_REL_IDENT, false>(buf0, p, 0, tile, gt, ix, cadj, acc, bfrag);
+        else ring_prime<F>(bfrag, reinterpret_cast<const uint4 *>(p.rel[0].wp), wave, lane);
+    }
+    bool lds_col = false;
+    if (has_csr) {
+        int lo = 0;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            c0[rb] = __builtin_amdgcn_readfirstlane(c0[rb]);
+            c1[rb] = __builtin_amdgcn_readfirstlane(c1[rb]);
+            cadj[rb] = lo - c0[rb];               // global col index -> index into ix.col
+            lo += c1[rb] - c0[rb];
+        }
+        lds_col = lo <= IX::COLCAP;
+        if (lds_col) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                for (int j = tid; j < c1[rb] - c0[rb]; j += 512) ix.col[c0[rb] + cadj[rb] + j] = p.col[c0[rb] + j];
+        }
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            if (tid < len) ix.rp[rb * IX::RP + tid] = rpv[rb];
     } else if (has_rng) {
         for (int j = tid; j <= ROWS; j += 512) {
             const int64_t n = row0 + j < p.n_rows ? row0 + j : p.n_rows;
             ix.rng[j] = p.rowptr[n];
         }
     }
-    __syncthreads();
-    bool lds_col = false;
-    if (has_csr) {
-        int lo = 0;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {     // every thread computes the same (uniform) layout
-            const int c0 = ix.rp[rb * IX::RP], c1 = ix.rp[rb * IX::RP + nrc * 16];
-            cadj[rb] = __builtin_amdgcn_readfirstlane(lo - c0);   // global col index -> index into ix.col
-            lo += c1 - c0;
-        }
-        lds_col = __builtin_amdgcn_readfirstlane(lo) <= IX::COLCAP;
-        if (lds_col) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb) {
-                const int c0 = ix.rp[rb * IX::RP], c1 = ix.rp[rb * IX::RP + nrc * 16];
-                for (int j = tid; j < c1 - c0; j += 512) ix.col[c0 + cadj[rb] + j] = p.col[c0 + j];
-            }
-        }
-    }
-    // ---- active relations of this tile (wave 7 so that it overlaps the col copy of the others)
-    if (wave == 7) {
+    if (wave == 7) {     // active relations of this tile, in relation order
         bool on = false;
         if (lane < p.n_rel) {
-            const int mode = p.rel[lane].mode;
-            if (mode == LGCN_REL_CSR) {
-                const int r = p.rel[lane].ridx;
+            on = p.rel[lane].mode == LGCN_REL_IDENT;
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
-                    on = on || ix.rp[rb * IX::RP + r * 16 + 16] > ix.rp[rb * IX::RP + r * 16];
-            } else if (mode == LGCN_REL_RANGE) {
-                on = ix.rng[ROWS] > ix.rng[0];
-            } else {
-                on = true;
-            }
+            for (int rb = 0; rb < RB; ++rb) on = on | (a1[rb] > a0[rb]);
         }
         const unsigned long long m = __ballot(on);
         if (on) act[__popcll(m & ((1ull << lane) - 1ull))] = lane;
@@ -478,8 +554,8 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     // measured slower because it halves that occupancy.
     auto rel_at = [&](int i) { return __builtin_amdgcn_readfirstlane(act[i]); };
     auto gather = [&](uint16_t *dst, int ri) {
-        if (KIND == 1 && lds_col) gather_rel<RB, F, KIND, true>(dst, p, ri, tile, gt, ix, cadj);
-        else gather_rel<RB, F, KIND, false>(dst, p, ri, tile, gt, ix, cadj);
+        if (KIND == 1 && lds_col) gather_rel<RB, F, KIND, true>(dst, p, ri, tile, gt, ix, cadj, acc, bfrag);
+        else gather_rel<RB, F, KIND, false>(dst, p, ri, tile, gt, ix, cadj, acc, bfrag);
     };
     if (!early) {
         if (wave >= 4) {
@@ -493,7 +569,6 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     }
     LGCN_STAMP(3);
 
-    f32x4 acc[RB][2];
     acc_zero<RB>(acc);
     for (int i = 0; i < nact; ++i) {
         uint16_t *cur = (i & 1) ? buf1 : buf0;
@@ -512,6 +587,12 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
         LGCN_STAMP(5 + 2 * i);       // barrier passed
     }
 
+    // ---- epilogue.  The MFMA waves own the accumulators and the second GEMM; the row phases (GroupNorm,
+    // residual, ReLU, stores) run on waves 4..7, which have finished gathering: the residual rows are
+    // requested before the first row phase and arrive under it and the second GEMM, and the MFMA waves
+    // fetch the second weight's fragments while the rows are normalised.
+    constexpr int NCH = (ROWS + 31) / 32;       // 32-row chunks of the row phase (8 threads per row)
+    const int rt = (tid - 256) & 255;           // row-phase thread id (masked: lets the compiler drop row < ROWS)
     if (wave < 4) {
         if (p.w4 != nullptr) {  // rank-4 fp32 update: the 4 meta channels of A2M.meta
 #pragma unroll
@@ -535,25 +616,40 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     __syncthreads();
     LGCN_STAMP(41);
 
-    if (tid < 256) {
+    RowVals resv[NCH];      // residual rows: requested here, used after GroupNorm (one stage) or after the second GEMM
+    if (wave >= 4) {
+        {   // branch-free (row clamped, p.out read and ignored without a residual): behind a branch or a
+            // predicate the compiler waits for these loads at the join, i.e. before the row phase starts
+            const float *rbase = (flags & LGCN_F_RES) ? p.res : p.out;
 #pragma unroll
-        for (int c0 = 0; c0 < ROWS; c0 += 32) {
-            const int row = c0 + (tid >> 3);
+            for (int ch = 0; ch < NCH; ++ch) {
+                const int row = 32 * ch + (rt >> 3);
+                const int64_t n = row0 + row;
+                const float *rp_ = rbase + (row < ROWS && n < p.n_rows ? n : 0) * kC + 4 * (rt & 7);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) resv[ch].v[j] = *reinterpret_cast<const float4 *>(rp_ + 32 * j);
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int row = 32 * ch + (rt >> 3);
             if (row < ROWS) {
                 const int64_t n = row0 + row;
                 const bool live = n < p.n_rows;
-                RowVals r = row_load(T + c0 * kLDA, tid);
+                RowVals r = row_load(T + 32 * ch * kLDA, rt);
 #ifndef LGCN_STAMPS
-                if (live && p.out_pre) row_store_global(p.out_pre + n * kC, tid, r);
+                if (live && p.out_pre) row_store_global(p.out_pre + n * kC, rt, r);
 #endif
-                if (flags & LGCN_F_GN1) row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
-                if (!two && live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
+                if (flags & LGCN_F_GN1) row_gn(r, rt, gnp, gnp + kC, p.eps);
+                if (!two && live && (flags & LGCN_F_RES)) row_add(r, resv[ch]);
                 if (flags & LGCN_F_RELU1) row_relu(r);
-                if (two && live && p.out_mid) row_store_global(p.out_mid + n * kC, tid, r);
-                if (two) row_split_store<F>(Yp, TL::PLANE, row, tid, r);
-                else if (live) row_store_global(p.out + n * kC, tid, r);
+                if (two && live && p.out_mid) row_store_global(p.out_mid + n * kC, rt, r);
+                if (two) row_split_store<F>(Yp, TL::PLANE, row, rt, r);
+                else if (live) row_store_global(p.out + n * kC, rt, r);
             }
         }
+    } else if (two) {
+        gemm2_prefetch<F>(bfrag, reinterpret_cast<const uint4 *>(p.wp2), wave, lane);
     }
     if (!two) return;
     LGCN_STAMP(42);
@@ -561,25 +657,25 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     LGCN_STAMP(43);
     if (wave < 4) {
         acc_zero<RB>(acc);
-        gemm_pass<RB, F>(Yp, reinterpret_cast<const uint4 *>(p.wp2), nullptr, bfrag, wave, lane, acc);
+        gemm2_pass<RB, F>(Yp, reinterpret_cast<const uint4 *>(p.wp2), bfrag, wave, lane, acc);
         acc_store<RB>(T, acc, lane, wave);   // T and Yp are disjoint; T's readers passed the barrier above
     }
     LGCN_STAMP(44);
     __syncthreads();
     LGCN_STAMP(45);
-    if (tid < 256) {
+    if (wave >= 4) {
 #pragma unroll
-        for (int c0 = 0; c0 < ROWS; c0 += 32) {
-            const int row = c0 + (tid >> 3);
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int row = 32 * ch + (rt >> 3);
             if (row < ROWS) {
                 const int64_t n = row0 + row;
                 const bool live = n < p.n_rows;
-                RowVals r = row_load(T + c0 * kLDA, tid);
-                if (live && p.out_pre2) row_store_global(p.out_pre2 + n * kC, tid, r);
-                if (flags & LGCN_F_GN2) row_gn(r, tid, p.gn2_g, p.gn2_b, p.eps);
-                if (live && (flags & LGCN_F_RES)) row_add_global(r, p.res + n * kC, tid);
+                RowVals r = row_load(T + 32 * ch * kLDA, rt);
+                if (live && p.out_pre2) row_store_global(p.out_pre2 + n * kC, rt, r);
+                if (flags & LGCN_F_GN2) row_gn(r, rt, gnp + 2 * kC, gnp + 3 * kC, p.eps);
+                if (live && (flags & LGCN_F_RES)) row_add(r, resv[ch]);
                 if (flags & LGCN_F_RELU2) row_relu(r);
-                if (live) row_store_global(p.out + n * kC, tid, r);
+                if (live) row_store_global(p.out + n * kC, rt, r);
             }
         }
     }
@@ -592,7 +688,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
 
 template <int RB, int F, int KIND, bool DEEP>
 __global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, DEEP) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4 + 4 * kC * 4];
     agg_body<RB, F, KIND, DEEP>(p, n_tiles, blockIdx.x, smem);
 }
 
@@ -601,7 +697,7 @@ __global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, DEEP) void k_agg_mlp_b
 template <int RB, int F>
 __global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, false) void k_agg_mlp_bf2(const lgcn_agg_mlp_t pa, const lgcn_agg_mlp_t pb, int tiles_a,
                                                      int tiles_b) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4 + 4 * kC * 4];
     if ((int)blockIdx.x < tiles_a) agg_body<RB, F, 0, false>(pa, tiles_a, blockIdx.x, smem);
     else agg_body<RB, F, 0, false>(pb, tiles_b, blockIdx.x - tiles_a, smem);
 }

@@ -23,10 +23,20 @@ __device__ __forceinline__ void row_store_lds(float *T, int t, const RowVals &r)
     for (int j = 0; j < 4; ++j) *reinterpret_cast<float4 *>(p + 32 * j) = r.v[j];
 }
 
-__device__ __forceinline__ float sum8(float x) {  // over the 8 lanes that share a row
-    x += __shfl_xor(x, 1, 64);
-    x += __shfl_xor(x, 2, 64);
-    x += __shfl_xor(x, 4, 64);
+// Cross-lane move by a DPP control word (VALU speed; __shfl_xor compiles to ds_bpermute_b32, an LDS round
+// trip per step).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
+// Sum over the 8 consecutive lanes that share a row; every lane gets the same bits as the xor-1/2/4 butterfly:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], then row_half_mirror (lane i <- lane 7 - i of its group of 8,
+// which sits in the other quad and holds that quad's sum).
+__device__ __forceinline__ float sum8(float x) {
+    x += dpp_mov<0xB1>(x);
+    x += dpp_mov<0x4E>(x);
+    x += dpp_mov<0x141>(x);
     return x;
 }
 
@@ -71,6 +81,13 @@ __device__ __forceinline__ void row_add_global(RowVals &r, const float *__restri
     for (int j = 0; j < 4; ++j) {
         const float4 x = *reinterpret_cast<const float4 *>(p + 32 * j);
         r.v[j].x += x.x; r.v[j].y += x.y; r.v[j].z += x.z; r.v[j].w += x.w;
+    }
+}
+
+__device__ __forceinline__ void row_add(RowVals &r, const RowVals &x) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.v[j].x += x.v[j].x; r.v[j].y += x.v[j].y; r.v[j].z += x.v[j].z; r.v[j].w += x.v[j].w;
     }
 }
 

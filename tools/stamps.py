@@ -45,7 +45,7 @@ def main():
     mf, ga = st[:, 0, :] - t0, st[:, 1, :] - t0
     med = lambda a: float(np.median(a))
     print("rb=%d mma=%s tiles=%d  (cycles, median over workgroups; 100 MHz memtime? see total)" % (rb, ops.get_mma(), n_tiles))
-    print("kernel span per WG (MFMA wave 0: stamp46 - stamp0): %.0f" % med(mf[:, 46]))
+    print("kernel span per WG (stamp46 of the row wave - stamp0): %.0f" % med(ga[:, 46]))
     print("  index preload + act (0->1): %.0f" % med(mf[:, 1]))
     print("  index ready -> loop start (1->3; relation 0 is fetched before the index slice): MFMA %.0f, gather %.0f" % (
         med(mf[:, 3] - mf[:, 1]), med(ga[:, 3] - ga[:, 1])))
@@ -58,11 +58,13 @@ def main():
     print("  per pass gather work:", " ".join("%5.0f" % v for v in work_g))
     print("  per pass gather wait:", " ".join("%5.0f" % v for v in wait_g))
     print("  loop total (3->33): %.0f" % med(mf[:, 33] - mf[:, 3]))
-    print("  epilogue: x4/acc store (33->40) %.0f | barrier %.0f | row phase 1 (41->42) %.0f | barrier %.0f | gemm2 (43->44) %.0f | barrier %.0f | row phase 2 (45->46) %.0f" % (
+    print("  epilogue, MFMA wave : acc store (33->40) %.0f | barrier %.0f | wp2 prefetch (41->42) %.0f | barrier %.0f | gemm2 (43->44) %.0f | barrier %.0f" % (
         med(mf[:, 40] - mf[:, 33]), med(mf[:, 41] - mf[:, 40]), med(mf[:, 42] - mf[:, 41]), med(mf[:, 43] - mf[:, 42]),
-        med(mf[:, 44] - mf[:, 43]), med(mf[:, 45] - mf[:, 44]), med(mf[:, 46] - mf[:, 45])))
+        med(mf[:, 44] - mf[:, 43]), med(mf[:, 45] - mf[:, 44])))
+    print("  epilogue, row wave  : wait (33->41) %.0f | row phase 1 (41->42) %.0f | barrier+gemm2 wait (42->45) %.0f | row phase 2 (45->46) %.0f" % (
+        med(ga[:, 41] - ga[:, 33]), med(ga[:, 42] - ga[:, 41]), med(ga[:, 45] - ga[:, 42]), med(ga[:, 46] - ga[:, 45])))
     start = st[:, 0, 0]
-    end = st[:, 0, 46]
+    end = st[:, 1, 46]
     print("  launch skew: first WG start -> last WG start %.0f ; first start -> last end %.0f" % (start.max() - start.min(), end.max() - start.min()))
 
 
