@@ -185,14 +185,18 @@ __device__ __forceinline__ bool within(float ax, float ay, float cx, float cy, f
     return __fsqrt_rn(d2) <= th;
 }
 
-// One wave per target row.  PASS 0 counts, PASS 1 writes (hi, wi).
+// One wave per target row.  PASS 0 counts, PASS 1 writes (hi, wi) and the segment table of the later
+// index_add_(0, hi, .):  rowptr_q[h] = first p with hi[p] >= h.  hi is non-decreasing and a row g of a scene that
+// advances the numbering owns h = hval(g), so rowptr_q[hval(g)] = rowptr[g]; rows of scenes that do not advance
+// it (legacy: scenes without pairs) fill the tail [h_used, T), where no pair can follow: P.  rowptr_q[T] = P.
 template <int PASS>
 __global__ __launch_bounds__(256) void k_pairs_rows(const float2 *agt, const int32_t *agt_off,
                                                     const float2 *ctx, const int32_t *ctx_off,
                                                     int n_scenes, int n_agt, float th,
                                                     int32_t *rowcnt, const int32_t *rowptr,
                                                     const int32_t *hi_base, const int32_t *wi_base,
-                                                    int32_t *hi, int32_t *wi, int64_t cap) {
+                                                    int32_t *hi, int32_t *wi, int64_t cap, int legacy,
+                                                    int32_t *rowptr_q) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_agt) return;
@@ -206,6 +210,13 @@ __global__ __launch_bounds__(256) void k_pairs_rows(const float2 *agt, const int
         pos = rowptr[g];
         hval = g - agt_off[sc] + hi_base[sc];
         wbase = wi_base[sc] - c0;
+        if (lane == 0) {
+            const int P = rowptr[n_agt];
+            const bool advances = !legacy || rowptr[agt_off[sc + 1]] - rowptr[agt_off[sc]] > 0;
+            if (advances) rowptr_q[hval] = (int)pos;
+            else rowptr_q[hi_base[n_scenes] + g - hi_base[sc]] = P;
+            if (g == 0) rowptr_q[n_agt] = P;
+        }
     }
     for (int s0 = c0; s0 < c1; s0 += 64) {
         const int s = s0 + lane;
@@ -228,20 +239,34 @@ __global__ __launch_bounds__(256) void k_pairs_rows(const float2 *agt, const int
     if (PASS == 0 && lane == 0) rowcnt[g] = count;
 }
 
-// Per-scene index bases (lanegcn.py:681-687).  legacy: a scene without pairs
-// does not advance the running counts.  Also publishes P.
-__global__ __launch_bounds__(1024) void k_pairs_bases(const int32_t *rowptr, const int32_t *agt_off,
-                                                      const int32_t *ctx_off, int n_scenes, int n_agt,
-                                                      int legacy, int64_t cap, int32_t *hi_base,
-                                                      int32_t *wi_base, int32_t *n_pairs) {
+// Single block: exclusive scan of the row counts in place (rp[0..T), rp[T] = P; each thread owns a contiguous
+// run), then the per-scene index bases (lanegcn.py:681-687; legacy: a scene without pairs does not advance the
+// running counts), hi_base[n_scenes] = rows numbered in all (h_used), and P.  The pair search has at most a few
+// 10^4 rows, so one block replaces four launches.
+__global__ __launch_bounds__(1024) void k_pairs_scan_bases(int32_t *rp, int n_agt, const int32_t *agt_off,
+                                                           const int32_t *ctx_off, int n_scenes, int legacy, int64_t cap,
+                                                           int32_t *hi_base, int32_t *wi_base, int32_t *n_pairs) {
     __shared__ int lds[1024 / 64 + 1];
+    const int per = (n_agt + 1024) / 1024;                  // ceil((T + 1) / 1024)
+    const int64_t b = (int64_t)threadIdx.x * per;
+    const int64_t e = b + per < (int64_t)n_agt + 1 ? b + per : (int64_t)n_agt + 1;
+    int sum = 0;
+    for (int64_t i = b; i < e; ++i) sum += i < n_agt ? rp[i] : 0;    // rp[T] holds no count
+    int tot;
+    int off = block_exclusive_scan<1024>(sum, &tot, lds);
+    for (int64_t i = b; i < e; ++i) {
+        const int v = i < n_agt ? rp[i] : 0;
+        rp[i] = off;
+        off += v;
+    }
+    __syncthreads();    // the scanned table is read across threads below
     int carry_h = 0, carry_w = 0;
     for (int c = 0; c < n_scenes; c += 1024) {
         const int i = c + threadIdx.x;
         int th = 0, tw = 0;
         if (i < n_scenes) {
             const int a0 = agt_off[i], a1 = agt_off[i + 1];
-            const bool nonempty = rowptr[a1] - rowptr[a0] > 0;
+            const bool nonempty = rp[a1] - rp[a0] > 0;
             if (!legacy || nonempty) { th = a1 - a0; tw = ctx_off[i + 1] - ctx_off[i]; }
         }
         int tot_h, tot_w;
@@ -252,24 +277,9 @@ __global__ __launch_bounds__(1024) void k_pairs_bases(const int32_t *rowptr, con
         carry_w += tot_w;
     }
     if (threadIdx.x == 0) {
-        const int P = rowptr[n_agt];
-        *n_pairs = (int64_t)P > cap ? -P : P;
+        hi_base[n_scenes] = carry_h;
+        *n_pairs = (int64_t)tot > cap ? -tot : tot;
     }
-}
-
-// rowptr_q[h] = first p with hi[p] >= h (hi is non-decreasing).
-__global__ __launch_bounds__(256) void k_pairs_rowptr(const int32_t *hi, const int32_t *n_pairs,
-                                                      int64_t cap, int n_agt, int32_t *rowptr_q) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h > n_agt) return;
-    int P = *n_pairs;
-    if (P < 0) P = (int)cap;
-    int lo = 0, hi_ = P;  // answer in [lo, hi_]
-    while (lo < hi_) {
-        const int mid = (lo + hi_) >> 1;
-        if (hi[mid] >= h) hi_ = mid; else lo = mid + 1;
-    }
-    rowptr_q[h] = lo;
 }
 
 __global__ __launch_bounds__(256) void k_widen(const int32_t *in, const int32_t *n_dev, int64_t cap, int64_t *out) {
@@ -369,8 +379,8 @@ int lgcn_csr_build(const int64_t *const *u_host, const int64_t *const *v_host, c
 
 int64_t lgcn_pairs_ws_elems(int64_t n_agt, int n_scenes) {
     if (n_agt < 0 || n_scenes < 0) return LGCN_EINVAL;
-    // rowptr_true [T+1] + scan sums + hi_base [B] + wi_base [B]
-    return (n_agt + 1) + scan_ws_elems(n_agt + 1) + 2 * (int64_t)n_scenes;
+    // rowptr_true [T+1] + hi_base [B+1] + wi_base [B]
+    return (n_agt + 1) + 2 * (int64_t)n_scenes + 1;
 }
 
 int lgcn_pairs_build(const float *agt_ctrs, const int32_t *agt_off, const float *ctx_ctrs,
@@ -387,29 +397,25 @@ int lgcn_pairs_build(const float *agt_ctrs, const int32_t *agt_off, const float 
     hipStream_t st = (hipStream_t)stream;
     const int T = (int)n_agt;
     int32_t *rp_true = ws;
-    int32_t *sums = rp_true + (T + 1);
-    int32_t *hi_base = sums + scan_ws_elems(T + 1);
-    int32_t *wi_base = hi_base + n_scenes;
-    // rowcnt[T] = 0 so that the exclusive scan over T+1 entries yields P at [T]
-    hipError_t e = hipMemsetAsync(rp_true + T, 0, sizeof(int32_t), st);
-    if (e != hipSuccess) return (int)e;
+    int32_t *hi_base = rp_true + (T + 1);
+    int32_t *wi_base = hi_base + n_scenes + 1;
+    // three launches: count per target row, scan + per-scene bases (one block), fill (+ segment table)
     const unsigned row_blocks = (unsigned)((T + 3) / 4);
     if (T > 0) {
         hipLaunchKernelGGL((k_pairs_rows<0>), dim3(row_blocks), dim3(256), 0, st,
                            (const float2 *)agt_ctrs, agt_off, (const float2 *)ctx_ctrs, ctx_off, n_scenes, T,
-                           dist_th, rp_true, nullptr, nullptr, nullptr, nullptr, nullptr, (int64_t)0);
+                           dist_th, rp_true, nullptr, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 0, nullptr);
     }
-    int rc = exclusive_scan(rp_true, rp_true, (int64_t)T + 1, sums, st);
-    if (rc != LGCN_OK) return rc;
-    hipLaunchKernelGGL(k_pairs_bases, dim3(1), dim3(1024), 0, st, rp_true, agt_off, ctx_off, n_scenes, T,
+    hipLaunchKernelGGL(k_pairs_scan_bases, dim3(1), dim3(1024), 0, st, rp_true, T, agt_off, ctx_off, n_scenes,
                        legacy_offsets, cap, hi_base, wi_base, n_pairs);
     if (T > 0) {
         hipLaunchKernelGGL((k_pairs_rows<1>), dim3(row_blocks), dim3(256), 0, st,
                            (const float2 *)agt_ctrs, agt_off, (const float2 *)ctx_ctrs, ctx_off, n_scenes, T,
-                           dist_th, nullptr, rp_true, hi_base, wi_base, hi, wi, cap);
+                           dist_th, nullptr, rp_true, hi_base, wi_base, hi, wi, cap, legacy_offsets, rowptr);
+    } else {
+        hipError_t e = hipMemsetAsync(rowptr, 0, sizeof(int32_t), st);    // rowptr_q[0] = P = 0
+        if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL(k_pairs_rowptr, dim3((unsigned)((T + 1 + 255) / 256)), dim3(256), 0, st,
-                       hi, n_pairs, cap, T, rowptr);
     return launch_status();
 }
 

@@ -308,7 +308,8 @@ struct TileIdx {
 // sweep over the 4 gather waves, 2 RB sweeps.  All first-edge loads of the sweeps are issued before any is
 // used, and the second-edge loads of rows that have one go out with them, so a pass costs ONE global round
 // trip for in-degree <= 2 (the common case: lane graphs branch rarely) and one more per further edge of the
-// widest row, instead of one per sweep.  Edges are summed in index order, as the f32 kernel and the oracle do.
+// widest row, instead of one per sweep.  Edges are summed in index order (as the f32 kernel and a sequential
+// index_add_ do).
 // LDSCOL: the tile's col entries are in LDS (ix.col, local index = global index + cadj[sub-tile]).
 // MODE is a template parameter so that each mode's index reads and row loads are issued as straight-line batches.
 //
@@ -373,6 +374,15 @@ __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const l
     auto load = [&](unsigned r) -> f32x4 { return src[((uint64_t)r << 5) + l]; };
     // edges j .. e-1 of one row added to acc in index order, four loads in flight
     auto tail = [&](f32x4 acc, int j, int end) -> f32x4 {
+        if (MODE == LGCN_REL_RANGE) {    // Att segment sums: tens of rows per target, eight in flight
+            for (; j + 7 < end; j += 8) {
+                f32x4 y[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) y[q] = load(row_of(j + q));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) acc = acc + y[q];
+            }
+        }
         for (; j + 3 < end; j += 4) {
             const f32x4 y0 = load(row_of(j)), y1 = load(row_of(j + 1)), y2 = load(row_of(j + 2)), y3 = load(row_of(j + 3));
             acc = (((acc + y0) + y1) + y2) + y3;
@@ -913,7 +923,7 @@ int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st) {
     if (rb < 0 || rb > 4) return LGCN_EINVAL;
     if (rb == 0 && lane_conv && force_rb_lc >= 1 && force_rb_lc <= 4) rb = force_rb_lc;
     if (rb == 0) rb = force_rb >= 1 && force_rb <= 4 ? force_rb : pick_rb(p.n_rows, 1);
-    const bool deep = ring >= 3;
+    const bool deep = ring >= 3;   // measured: no gain for the small row blocks either (U/V, Att tails)
     switch (fmt_of(p.mma)) {
         case 0: if (deep) launch_agg<0, true>(p, rb, lane_conv, st); else launch_agg<0, false>(p, rb, lane_conv, st); break;
         case 1: if (deep) launch_agg<1, true>(p, rb, lane_conv, st); else launch_agg<1, false>(p, rb, lane_conv, st); break;
