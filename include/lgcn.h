@@ -154,6 +154,16 @@ int lgcn_pack_weight(const float *W, int ld, int k_real, int k_pad, int mma,
  * backward of y = x W^T is dx = dy W, i.e. a Linear whose weight is W^T. */
 int lgcn_pack_weight_t(const float *W, int ld, int mma, void *out, void *stream);
 
+/* Many [128,128] blocks in one launch: what a training loop does after every optimizer step (train.py:190,
+ * the weights change in place) instead of ~400 single launches.  `jobs` is a DEVICE array. */
+typedef struct {
+    const float *W;          /* top-left element of the [128,128] block (row stride ld) */
+    void *out;               /* packed image, lgcn_packed_bytes(128, mma) bytes         */
+    int32_t ld;
+    int32_t transpose;       /* 0: lgcn_pack_weight, 1: lgcn_pack_weight_t             */
+} lgcn_pack_job_t;
+int lgcn_pack_weight_batch(const lgcn_pack_job_t *jobs, int n_jobs, int mma, void *stream);
+
 /* One relation of an aggregate-GEMM stage (see lgcn_agg_mlp). */
 typedef struct {
     const float *src;        /* [*,128] source rows                        */

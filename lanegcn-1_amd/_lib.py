@@ -50,6 +50,7 @@ SIGNATURES = {
     "lgcn_packed_bytes": (C.c_int64, [_I, _I]),
     "lgcn_pack_weight": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),
     "lgcn_pack_weight_t": (C.c_int, [_P, _I, _I, _P, _P]),
+    "lgcn_pack_weight_batch": (C.c_int, [_P, _I, _I, _P]),
     "lgcn_agg_mlp": (C.c_int, [C.POINTER(AggMlp), _P]),
     "lgcn_agg_mlp_pair": (C.c_int, [C.POINTER(AggMlp), C.POINTER(AggMlp), _P]),
     "lgcn_gn_bwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _P, _P]),

@@ -55,6 +55,15 @@ __global__ __launch_bounds__(256) void k_pack_weight(const float *__restrict__ W
     }
 }
 
+__global__ __launch_bounds__(256) void k_pack_weight_batch(const lgcn_pack_job_t *__restrict__ jobs) {
+    const lgcn_pack_job_t job = jobs[blockIdx.y];
+    float *__restrict__ out = reinterpret_cast<float *>(job.out);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;      // < 128 * 128
+    const int j = i & 3, lane = (i >> 2) & 63, q = (i >> 8) % (kC >> 3), w = (i >> 8) / (kC >> 3);
+    const int row = 32 * w + (lane & 31), k = 8 * q + 4 * (lane >> 5) + j;
+    out[i] = job.transpose ? job.W[(int64_t)k * job.ld + row] : job.W[(int64_t)row * job.ld + k];
+}
+
 // ------------------------------------------------------------ agg_mlp -----
 // 8 waves: waves 0-3 run the MFMA chain of relation i while waves 4-7 gather
 // relation i+1 into the other LDS buffer (one barrier per relation).
@@ -486,6 +495,15 @@ int lgcn_pack_weight_t(const float *W, int ld, int mma, void *out, void *stream)
     if (mma != LGCN_MMA_F32) return pack_weight_bf(W, ld, mma, 1, out, (hipStream_t)stream);
     hipLaunchKernelGGL(k_pack_weight, dim3(kC * kC / 256), dim3(256), 0, (hipStream_t)stream, W, ld, kC, kC,
                        reinterpret_cast<float *>(out), 1);
+    return launch_status();
+}
+
+int lgcn_pack_weight_batch(const lgcn_pack_job_t *jobs, int n_jobs, int mma, void *stream) {
+    if (!valid_mma(mma) || n_jobs < 0 || n_jobs > 65535) return LGCN_EINVAL;
+    if (n_jobs == 0) return LGCN_OK;
+    LGCN_CHECK_PTR(jobs);
+    if (mma != LGCN_MMA_F32) return pack_weight_batch_bf(jobs, n_jobs, mma, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_pack_weight_batch, dim3(kC * kC / 256, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
     return launch_status();
 }
 

@@ -262,10 +262,9 @@ __device__ __forceinline__ void row_split_store(uint16_t *planes, int plane_elem
 
 // ------------------------------------------------------------ packing -----
 template <int F>
-__global__ __launch_bounds__(256) void k_pack_weight_bf(const float *__restrict__ W, int ld, uint16_t *__restrict__ out,
-                                                        int transpose) {
+__device__ __forceinline__ void pack_block_bf(const float *__restrict__ W, int ld, uint16_t *__restrict__ out, int transpose,
+                                              int i) {
     // one thread per (w, s, cb, lane): 8 consecutive k of one weight row -> 8 elements per plane
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 4 * 4 * 2 * 64) return;
     const int lane = i & 63, cb = (i >> 6) & 1, s = (i >> 7) & 3, w = i >> 9;
     const int orow = 32 * w + 16 * cb + (lane & 15), k0 = 32 * s + 8 * (lane >> 4);
@@ -285,6 +284,18 @@ __global__ __launch_bounds__(256) void k_pack_weight_bf(const float *__restrict_
         uint4 *dst = reinterpret_cast<uint4 *>(out) + ((((p * 4 + w) * 4 + s) * 2 + cb) << 6) + lane;
         *dst = make_uint4(q[0], q[1], q[2], q[3]);
     }
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void k_pack_weight_bf(const float *__restrict__ W, int ld, uint16_t *__restrict__ out,
+                                                        int transpose) {
+    pack_block_bf<F>(W, ld, out, transpose, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+template <int F>
+__global__ __launch_bounds__(256) void k_pack_weight_batch_bf(const lgcn_pack_job_t *__restrict__ jobs) {
+    const lgcn_pack_job_t job = jobs[blockIdx.y];
+    pack_block_bf<F>(job.W, job.ld, reinterpret_cast<uint16_t *>(job.out), job.transpose, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ------------------------------------------------------------ agg_mlp -----
@@ -984,6 +995,15 @@ int pack_weight_bf(const float *W, int ld, int mma, int transpose, void *out, hi
         case 0: hipLaunchKernelGGL((k_pack_weight_bf<0>), dim3(8), dim3(256), 0, st, W, ld, o, transpose); break;
         case 1: hipLaunchKernelGGL((k_pack_weight_bf<1>), dim3(8), dim3(256), 0, st, W, ld, o, transpose); break;
         default: hipLaunchKernelGGL((k_pack_weight_bf<2>), dim3(8), dim3(256), 0, st, W, ld, o, transpose); break;
+    }
+    return launch_status();
+}
+
+int pack_weight_batch_bf(const lgcn_pack_job_t *jobs, int n_jobs, int mma, hipStream_t st) {
+    switch (fmt_of(mma)) {
+        case 0: hipLaunchKernelGGL((k_pack_weight_batch_bf<0>), dim3(8, n_jobs), dim3(256), 0, st, jobs); break;
+        case 1: hipLaunchKernelGGL((k_pack_weight_batch_bf<1>), dim3(8, n_jobs), dim3(256), 0, st, jobs); break;
+        default: hipLaunchKernelGGL((k_pack_weight_batch_bf<2>), dim3(8, n_jobs), dim3(256), 0, st, jobs); break;
     }
     return launch_status();
 }

@@ -125,5 +125,6 @@ int agg_mlp_pair_bf(const lgcn_agg_mlp_t &a, const lgcn_agg_mlp_t &b, hipStream_
 int mapnet_input_bf(const InputParams &p, int mma, hipStream_t st);
 int att_pairs_bf(const PairParams &p, int mma, hipStream_t st);
 int pack_weight_bf(const float *W, int ld, int mma, int transpose, void *out, hipStream_t st);
+int pack_weight_batch_bf(const lgcn_pack_job_t *jobs, int n_jobs, int mma, hipStream_t st);
 
 }  // namespace lgcn

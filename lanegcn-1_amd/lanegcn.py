@@ -266,7 +266,7 @@ class MapNet(nn.Module):
             # (lanegcn.py:312-322) and therefore raises KeyError; kept for error parity
             raise KeyError("node_idcs")
         ctrs = torch.cat(graph["ctrs"], 0)
-        if _hot_guard(graph["feats"], *self.parameters()):
+        if _hot_guard(graph["feats"], *ops.module_params(self)):
             a, s = self.input, self.seg      # the two nn.Linear(2,128) are [N,2]-shaped: stock ops
             fa = A.linear_gn(F.relu(a[0](ctrs)), a[2].linear.weight, gn=a[2].norm)
             fs = A.linear_gn(F.relu(s[0](graph["feats"])), s[2].linear.weight, gn=s[2].norm)
@@ -287,7 +287,7 @@ class M2M(nn.Module):
         self.relu = nn.ReLU(inplace=True)
 
     def forward(self, feat: Tensor, graph: Dict) -> Tensor:
-        if _hot_guard(feat, *self.parameters()):
+        if _hot_guard(feat, *ops.module_params(self)):
             return lane_conv_train(self.fuse, feat, lane_plan(graph), lane_plan_t(graph), len(graph["pre"]))
         return lane_conv(self.fuse, feat, lane_plan(graph), len(graph["pre"]))
 
@@ -331,7 +331,7 @@ class Att(nn.Module):
     def forward(self, agts: Tensor, agt_idcs: List[Tensor], agt_ctrs: List[Tensor], ctx: Tensor,
                 ctx_idcs: List[Tensor], ctx_ctrs: List[Tensor], dist_th: float,
                 pairs: Optional[ops.PairSet] = None) -> Tensor:
-        train = _hot_guard(agts, ctx, *self.parameters())
+        train = _hot_guard(agts, ctx, *ops.module_params(self))
         T = agts.shape[0]
         lin = self.linear
         if len(ctx) == 0:   # lanegcn.py:664-670: no GroupNorm before the ReLU
@@ -420,7 +420,7 @@ class A2M(nn.Module):
 
     def forward(self, feat: Tensor, graph: Dict, actors: Tensor, actor_idcs: List[Tensor],
                 actor_ctrs: List[Tensor]) -> Tensor:
-        if _hot_guard(feat, actors, *self.parameters()):
+        if _hot_guard(feat, actors, *ops.module_params(self)):
             w = self.meta.linear.weight       # 132 = 128 (HIP row block) + 4 meta columns ([N,4]: stock op)
             meta4 = torch.cat((graph["turn"], graph["control"].unsqueeze(1), graph["intersect"].unsqueeze(1)), 1)
             feat = A.gn_act(A.linear_gn(feat, w, col0=0) + F.linear(meta4, w[:, 128:132]), gn=self.meta.norm, relu=True)
@@ -582,7 +582,7 @@ class Net(nn.Module):
         self.pred_net = PredNet(config)
 
     def forward(self, data: Dict) -> Dict[str, List[Tensor]]:
-        if not ops.wants_grad(*self.parameters()) and len(data["feats"]) > 0 and sum(len(x) for x in data["ctrs"]) > 0:
+        if not ops.wants_grad(*ops.module_params(self)) and len(data["feats"]) > 0 and sum(len(x) for x in data["ctrs"]) > 0:
             return self._forward_inference(data)
         actors, actor_idcs = actor_gather(gpu(data["feats"]))
         actor_ctrs = gpu(data["ctrs"])

@@ -64,7 +64,7 @@ class Linear(nn.Module):
     def forward(self, x):
         if self._hot_shaped(x):
             # the graph hot path's shape: HIP only (CUDA tensors, no CPU fallback)
-            if ops.wants_grad(x, *self.parameters()):
+            if ops.wants_grad(x, *ops.module_params(self)):
                 from . import autograd as A
                 return A.linear_gn(x, self.linear.weight, gn=self.norm, relu=self.act)
             flags = L.F_GN1 | (L.F_RELU1 if self.act else 0)
@@ -141,7 +141,7 @@ class LinearRes(nn.Module):
             # 128 -> 128: the fused two-stage row block of the hot path (one launch; PredNet heads, lanegcn.py:587-600)
             from . import autograd as A
             x = x.contiguous()
-            if ops.wants_grad(x, *self.parameters()):
+            if ops.wants_grad(x, *ops.module_params(self)):
                 spec = A.BlockSpec(n_rows=x.shape[0], rels=[A.Rel(0, 0, L.REL_IDENT)], gn=True, relu=True, has_res=True,
                                    eps=self.norm1.eps)
                 return A.LaneConvFn.apply(spec, x, self.norm1.weight, self.norm1.bias, self.linear2.weight,

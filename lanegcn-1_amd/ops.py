@@ -52,7 +52,17 @@ class backward_mma:
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    # the raw hipStream_t of torch's current stream (torch.cuda.current_stream() costs ~9 us of Python per call)
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+
+
+def module_params(module) -> tuple:
+    """tuple(module.parameters()), cached on the module (walking the module tree costs more than a launch)."""
+    ps = module.__dict__.get("_lgcn_params")
+    if ps is None:
+        ps = tuple(module.parameters())
+        module.__dict__["_lgcn_params"] = ps
+    return ps
 
 
 def _dev(t: torch.Tensor, dtype=None, name="tensor"):
@@ -213,6 +223,53 @@ def invalidate_packed(weight: torch.Tensor):
     weight.__dict__.pop("_lgcn_cache", None)
 
 
+# Every cached [128,128] image is also listed here, so that a training loop can rebuild all of them after an
+# optimizer step with ONE launch (lgcn_pack_weight_batch) instead of ~400 single ones on first use.
+_pack_jobs = []        # [weakref(weight), cache key, out, col0, transpose, mma]
+_pack_tables = {}      # mma -> (job ids, device table [n,3] int64) of the last full refresh
+
+
+def _register_pack(weight, key, out, col0, transpose, mma):
+    import weakref
+    _pack_jobs.append([weakref.ref(weight), key, out, col0, transpose, mma])
+
+
+def refresh_packed() -> int:
+    """Re-pack, in place, every registered image whose parameter changed since it was packed (optimizer step:
+    reference train.py:190).  One launch per matrix-core mode in use.  Returns the number of images rebuilt."""
+    if not _pack_jobs:
+        return 0
+    lib = L.load()
+    stale = {}
+    alive = []
+    for job in _pack_jobs:
+        w = job[0]()
+        if w is None:
+            continue
+        entry = w.__dict__.get("_lgcn_cache", {}).get(job[1])
+        if entry is None or entry[1] is not job[2] or not w.is_cuda:
+            continue                     # cache entry dropped or replaced: nothing to refresh
+        alive.append(job)
+        if entry[0] != (w.data_ptr(), w._version, w.device):
+            stale.setdefault(job[5], []).append((job, w))
+    _pack_jobs[:] = alive
+    n = 0
+    for mma, items in stale.items():
+        ids = tuple(id(j) for j, _ in items)
+        hit = _pack_tables.get(mma)
+        if hit is not None and hit[0] == ids and all(h == w.data_ptr() for h, (_, w) in zip(hit[2], items)):
+            table = hit[1]
+        else:
+            rows = [[w.data_ptr() + 4 * j[3], j[2].data_ptr(), w.stride(0) | (int(j[4]) << 32)] for j, w in items]
+            table = torch.tensor(rows, dtype=torch.int64).to(items[0][1].device)
+            _pack_tables[mma] = (ids, table, [w.data_ptr() for _, w in items])
+        L.check(lib.lgcn_pack_weight_batch(_ptr(table), len(items), mma, _stream()), "lgcn_pack_weight_batch")
+        for j, w in items:
+            w.__dict__["_lgcn_cache"][j[1]] = ((w.data_ptr(), w._version, w.device), j[2])
+        n += len(items)
+    return n
+
+
 def packed(weight: torch.Tensor, col0: int = 0, k: Optional[int] = None) -> torch.Tensor:
     """MFMA-packed image of weight[:, col0:col0+k] ([128, k] slice of an nn.Linear weight); cached
     on the parameter and rebuilt only after the parameter changes."""
@@ -233,6 +290,8 @@ def packed(weight: torch.Tensor, col0: int = 0, k: Optional[int] = None) -> torc
         src = w[:, col0:]
         L.check(lib.lgcn_pack_weight(C.c_void_p(src.data_ptr()), w.stride(0), k, k_pad, mma, _ptr(out), _stream()),
                 "lgcn_pack_weight")
+        if k == C_FEAT:
+            _register_pack(weight, ("pack", col0, k, mma), out, col0, 0, mma)
         return out
 
     return _cached(weight, ("pack", col0, k, mma), make)
@@ -251,6 +310,7 @@ def packed_t(weight: torch.Tensor, col0: int = 0) -> torch.Tensor:
         out = torch.empty(lib.lgcn_packed_bytes(C_FEAT, mma) // 4, dtype=torch.float32, device=w.device)
         L.check(lib.lgcn_pack_weight_t(C.c_void_p(w[:, col0:].data_ptr()), w.stride(0), mma, _ptr(out), _stream()),
                 "lgcn_pack_weight_t")
+        _register_pack(weight, ("packT", col0, mma), out, col0, 1, mma)
         return out
 
     return _cached(weight, ("packT", col0, mma), make)

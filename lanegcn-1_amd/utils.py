@@ -75,6 +75,8 @@ class Optimizer(object):
         for c, g in zip(self.coef, self.opt.param_groups):
             g["lr"] = lr * c
         self.opt.step()
+        from . import ops
+        ops.refresh_packed()     # the MFMA images of the weights, rebuilt in one launch (else: one per weight on first use)
         return lr
 
     def clip(self):

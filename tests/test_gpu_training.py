@@ -251,3 +251,34 @@ def test_train_driver_smoke_and_resume(tmp_path):
                         "--resume", os.path.join(save, ckpts[0])])
     assert rc == 0
     assert train_dp.main(["--eval", "--weight", os.path.join(save, ckpts[0]), "--dataset-len", "4"]) == 0
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2", "bf16"])
+def test_refresh_packed_matches_single_packs(mode):
+    """After an in-place weight update, ONE lgcn_pack_weight_batch launch must leave every cached image (plain,
+    column-offset and transposed) bit-identical to a fresh single-weight pack."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import ops
+    prev = ops.get_mma()
+    ops.set_mma(mode)
+    try:
+        torch.manual_seed(3)
+        ws = [torch.nn.Parameter(torch.randn(128, 128, device="cuda")), torch.nn.Parameter(torch.randn(128, 384, device="cuda"))]
+        imgs = [ops.packed(ws[0]), ops.packed_t(ws[0]), ops.packed(ws[1], 128, 128), ops.packed_t(ws[1], 256)]
+        ptrs = [t.data_ptr() for t in imgs]
+        with torch.no_grad():
+            for w in ws:
+                w.add_(torch.randn_like(w))          # what optimizer.step() does: in place, bumps _version
+        n = ops.refresh_packed()
+        assert n >= 4
+        again = [ops.packed(ws[0]), ops.packed_t(ws[0]), ops.packed(ws[1], 128, 128), ops.packed_t(ws[1], 256)]
+        assert [t.data_ptr() for t in again] == ptrs            # cache hits: refreshed in place, not rebuilt
+        got = [t.clone() for t in again]
+        for w in ws:
+            ops.invalidate_packed(w)
+        fresh = [ops.packed(ws[0]), ops.packed_t(ws[0]), ops.packed(ws[1], 128, 128), ops.packed_t(ws[1], 256)]
+        for a, b in zip(got, fresh):
+            assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+        assert ops.refresh_packed() == 0                        # nothing stale
+    finally:
+        ops.set_mma(prev)
