@@ -281,7 +281,7 @@ int lgcn_gn_bwd(const float *dy, const float *x, const float *post, const float 
  *   dW[r] = dT^T (G_r src_r)      [128,128] per relation, fp32 (f32-input MFMA, exact fma chain)
  * The relations (src, mode, ridx), rowptr/col/n_rel_csr and n_rows are read from *p exactly as
  * lgcn_agg_mlp reads them (wp and the epilogue fields are ignored).
- * dW: [n_rel,128,128]; part: workspace of n_rel * n_chunks * 128*128 floats, n_chunks in 1..64.
+ * dW: [n_rel,128,128]; part: workspace of n_rel * n_chunks * 128*128 floats, n_chunks in 1..1024 (pick n_rel * n_chunks ~ 2 workgroups per CU).
  */
 int lgcn_wgrad(const lgcn_agg_mlp_t *p_host, const float *dT, float *dW, float *part,
                int n_chunks, void *stream);

@@ -616,7 +616,7 @@ int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs, const int32_t *
 int lgcn_wgrad(const lgcn_agg_mlp_t *ph, const float *dT, float *dW, float *part, int n_chunks, void *stream) {
     LGCN_CHECK_PTR(ph); LGCN_CHECK_PTR(dT); LGCN_CHECK_PTR(dW); LGCN_CHECK_PTR(part);
     const lgcn_agg_mlp_t &p = *ph;
-    if (p.n_rows < 0 || p.n_rel < 1 || p.n_rel > LGCN_MAX_REL || n_chunks < 1 || n_chunks > 64) return LGCN_EINVAL;
+    if (p.n_rows < 0 || p.n_rel < 1 || p.n_rel > LGCN_MAX_REL || n_chunks < 1 || n_chunks > 1024) return LGCN_EINVAL;
     if (p.n_rows > 0x7fffffff) return LGCN_ESHAPE;
     LGCN_CHECK_ALIGN16(dT); LGCN_CHECK_ALIGN16(dW); LGCN_CHECK_ALIGN16(part);
     bool need_rowptr = false, need_col = false;

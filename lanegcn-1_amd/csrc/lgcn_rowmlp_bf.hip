@@ -385,7 +385,7 @@ __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const l
     auto load = [&](unsigned r) -> f32x4 { return src[((uint64_t)r << 5) + l]; };
     // edges j .. e-1 of one row added to acc in index order, four loads in flight
     auto tail = [&](f32x4 acc, int j, int end) -> f32x4 {
-        if (MODE == LGCN_REL_RANGE) {    // Att segment sums: tens of rows per target, eight in flight
+        if (MODE == LGCN_REL_RANGE && RB == 1) {    // Att segment sums (tens of rows per target): eight in flight where registers allow
             for (; j + 7 < end; j += 8) {
                 f32x4 y[8];
 #pragma unroll
@@ -704,7 +704,8 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
 }
 
 // Tiles of <= 32 rows must keep two 8-wave workgroups per CU (4 waves per SIMD = 128 VGPRs): that co-residency
-// is what hides the weight-fragment latency; the register allocator is held to it.
+// is what hides the weight-fragment latency; the register allocator is held to it (also where that costs a few
+// spilled registers: three-plane bf16x3 at RB = 2 runs 52 us held to 128 VGPRs, 74 us left free).
 #define LGCN_WAVES_PER_SIMD(RB_, DEEP_) __attribute__((amdgpu_waves_per_eu((RB_) <= 2 && !(DEEP_) ? 4 : 2)))
 
 template <int RB, int F, int KIND, bool DEEP>
