@@ -458,3 +458,46 @@ def test_engine_at_twice_the_baseline_batch_vs_oracle(hip, ref_state_names):
     for got, (a, c, th) in zip(counts, ((0, 1, 7.0), (1, 0, 6.0), (1, 1, 100.0))):
         ctr = [[s["graph"]["ctrs"] for s in scenes], [s["ctrs"] for s in scenes]]
         assert got == len(O.pair_search(ctr[a], ctr[c], th)[0])
+
+
+def test_laneconv_on_a_multigraph_vs_oracle(hip, ref_state_names):
+    """Lane graphs branch rarely, real maps do merge: rows with in-degree 2, 3..9 and duplicate edges under one
+    relation, relations without edges, a node count that is no multiple of the tile.  Exercises the second-edge
+    loads and the > 2 tail of the gather (forward M2M = 4 LaneConv layers) against the oracle's index_add_ chain,
+    in the engine's fused path and at every tile height."""
+    M, ops = hip
+    rng = np.random.default_rng(17)
+    n = 16 * 23 + 5
+    sd = O.seeded_state(ref_state_names, 11)
+    m2m = make_modules(M, sd)["m2m"]
+
+    def edges(m, hot=False):
+        u = rng.integers(0, n, m)
+        if hot:                                   # a few destination rows collect most edges
+            u = np.where(rng.random(m) < 0.5, rng.integers(0, 12, m), u)
+        v = rng.integers(0, n, m)
+        return {"u": torch.from_numpy(u), "v": torch.from_numpy(v)}
+
+    graph = {"pre": [edges(m, hot=(i == 0)) for i, m in enumerate((900, 700, 0, 350, 40, 500))],
+             "suc": [edges(m) for m in (800, 0, 600, 300, 3, 450)],
+             "left": edges(260, hot=True), "right": edges(0)}
+    feat = torch.from_numpy(rng.normal(0, 1, (n, 128)).astype(np.float32)).relu()
+    want = O.m2m(feat, graph, sd).numpy()
+    deg = np.bincount(graph["pre"][0]["u"].numpy(), minlength=n)
+    assert deg.max() >= 9 and (deg == 2).any()
+    us, vs = [], []
+    for i in range(6):
+        for k1 in ("pre", "suc"):
+            us.append(graph[k1][i]["u"].cuda())
+            vs.append(graph[k1][i]["v"].cuda())
+    for k1 in ("left", "right"):
+        us.append(graph[k1]["u"].cuda())
+        vs.append(graph[k1]["v"].cuda())
+    with torch.no_grad():
+        plan = ops.csr_build(us, vs, n)
+        for rb in (0, 1, 2, 3, 4):
+            if rb and ops.get_mma() == "f32":
+                continue
+            got = M.lane_conv(m2m.fuse, feat.cuda(), plan, 6, tile_rb=rb).cpu().numpy()
+            err = float(np.abs(got - want).max())
+            assert err <= FTOL, (rb, err)
