@@ -56,7 +56,7 @@ def test_size_helpers(lib):
     assert l.lgcn_packed_bytes(136, 1) < 0 and l.lgcn_packed_bytes(128, 9) < 0
     assert l.lgcn_csr_rowptr_elems(10, 17) < 0
     assert l.lgcn_csr_ws_elems(10368, 14) > l.lgcn_csr_rowptr_elems(10368, 14)
-    assert l.lgcn_pairs_ws_elems(1600, 32) >= 1601 + 64
+    assert l.lgcn_pairs_ws_elems(1600, 32) == 1601 + 2 * 32 + 1 and l.lgcn_pairs_ws_elems(-1, 2) < 0
 
 
 def test_bad_arguments_are_refused_without_launching(lib):
@@ -95,6 +95,22 @@ def test_bad_arguments_are_refused_without_launching(lib):
     assert l.lgcn_att_pairs(*([None] * 5), 0, *([None] * 10), 1e-5, 0, None, None) == 0
     assert l.lgcn_att_pairs(*([None] * 5), 0, *([None] * 10), 1e-5, 9, None, None) == EINVAL
     assert l.lgcn_mapnet_input(None, None, 5, *([None] * 10), 1e-5, 1, None, None) == EINVAL
+    # one rowptr per launch: CSR and RANGE relations cannot be mixed
+    q = mod.AggMlp()
+    q.n_rows, q.n_rel, q.n_rel_csr, q.out, q.rowptr, q.col = 10, 2, 1, 256, 256, 256
+    q.rel[0].src, q.rel[0].wp, q.rel[0].mode, q.rel[0].ridx = 256, 256, mod.REL_CSR, 0
+    q.rel[1].src, q.rel[1].wp, q.rel[1].mode = 256, 256, mod.REL_RANGE
+    assert l.lgcn_agg_mlp(C.byref(q), None) == EINVAL
+    # batched weight pack: job count and table pointer
+    assert l.lgcn_pack_weight_batch(None, 0, 3, None) == 0
+    assert l.lgcn_pack_weight_batch(None, 4, 3, None) == EINVAL
+    assert l.lgcn_pack_weight_batch(C.c_void_p(256), -1, 3, None) == EINVAL
+    assert l.lgcn_pack_weight_batch(C.c_void_p(256), 4, 7, None) == EINVAL
+    # weight gradient: chunk count 1..1024
+    w = mod.AggMlp()
+    w.n_rows, w.n_rel = 64, 1
+    for bad in (0, 1025):
+        assert l.lgcn_wgrad(C.byref(w), C.c_void_p(256), C.c_void_p(256), C.c_void_p(256), bad, None) == EINVAL
 
 
 def test_product_never_imports_the_oracle():
