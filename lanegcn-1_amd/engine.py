@@ -43,6 +43,9 @@ class FlatBatch:
 
 def collate_flat(scenes: List[Dict], device=None, pin: bool = False) -> FlatBatch:
     """Host collate of scene dicts (numpy or CPU torch leaves) into a FlatBatch on `device`.
+    Every tensor is its own device allocation on purpose: packing them as views of three staging buffers (one
+    host-to-device copy per dtype) was measured to cost nothing on the host side but halved the throughput of four
+    captured forwards in flight (106 k -> 52 k scenes/s; cause not isolated), so it was reverted.
     pin: stage through pinned memory (asynchronous copies; allocating pinned buffers per call costs more than
     it saves for these ~2 MB batches, so a loader that wants it should reuse its own staging buffers)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -67,11 +70,11 @@ def collate_flat(scenes: List[Dict], device=None, pin: bool = False) -> FlatBatc
         nonlocal pos
         begin = pos
         for j, g in enumerate(graphs):
-            x = npy(getter(g)).reshape(-1)            # 0-dim guard (lanegcn.py:203-207)
+            x = npy(getter(g)).astype(np.int64).reshape(-1)   # 0-dim guard (lanegcn.py:203-207) + to_long
             pieces.append(x)
-            seg_len.append(x.shape[0])
+            seg_len.append(len(x))
             seg_base.append(node_off[j])
-            pos += x.shape[0]
+            pos += len(x)
         return (begin, pos)
 
     keys = []
@@ -89,31 +92,22 @@ def collate_flat(scenes: List[Dict], device=None, pin: bool = False) -> FlatBatc
         n_edges.append(su[1] - su[0])
     seg_off = np.zeros(len(seg_len) + 1, np.int64)
     np.cumsum(seg_len, out=seg_off[1:])
-    idx_local = np.concatenate(pieces).astype(np.int64, copy=False) if pieces else np.zeros(0, np.int64)   # to_long
 
-    # three host -> device copies (float32 / int64 / int32), the tensors of the batch are 16-byte aligned views
-    def pack(arrays, dtype, align):
-        offs, total = [], 0
-        for a in arrays:
-            offs.append(total)
-            total += (a.size + align - 1) // align * align
-        buf = np.zeros(max(total, align), dtype)
-        for a, o in zip(arrays, offs):
-            buf[o:o + a.size] = a.reshape(-1)
-        t = torch.from_numpy(buf)
-        if dev.type != "cpu":
-            t = t.pin_memory().to(dev, non_blocking=True) if pin else t.to(dev)
-        return [t[o:o + a.size].view(a.shape) for a, o in zip(arrays, offs)]
+    def up(a, dtype=None):
+        t = torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype)))
+        if dev.type == "cpu":
+            return t
+        return t.pin_memory().to(dev, non_blocking=True) if pin else t.to(dev)
 
     cat = lambda key, src: np.concatenate([npy(s[key]) for s in src], 0)
-    f32 = pack([cat("ctrs", graphs), cat("feats", graphs), cat("turn", graphs), cat("control", graphs),
-                cat("intersect", graphs), cat("ctrs", scenes)], np.float32, 4)
-    i64 = pack([idx_local, seg_off, np.asarray(seg_base, np.int64)], np.int64, 2)
-    i32 = pack([node_off, actor_off], np.int32, 4)
     return FlatBatch(
         n_scenes=B, n_nodes=int(node_off[-1]), n_actors=int(actor_off[-1]), num_scales=ns,
-        node_ctrs=f32[0], node_feats=f32[1], turn=f32[2], control=f32[3], intersect=f32[4], actor_ctrs=f32[5],
-        node_off=i32[0], actor_off=i32[1], idx_local=i64[0], seg_off=i64[1], seg_base=i64[2],
+        node_ctrs=up(cat("ctrs", graphs), np.float32), node_feats=up(cat("feats", graphs), np.float32),
+        turn=up(cat("turn", graphs), np.float32), control=up(cat("control", graphs), np.float32),
+        intersect=up(cat("intersect", graphs), np.float32), actor_ctrs=up(cat("ctrs", scenes), np.float32),
+        node_off=up(node_off, np.int32), actor_off=up(actor_off, np.int32),
+        idx_local=up(np.concatenate(pieces) if pieces else np.zeros(0, np.int64)),
+        seg_off=up(seg_off), seg_base=up(np.asarray(seg_base, np.int64)),
         rel_slices=rel_slices, cap_a2m=int(np.dot(n_nodes, n_act)), cap_a2a=int(np.dot(n_act, n_act)),
         n_edges=n_edges,
     )
