@@ -123,6 +123,55 @@ def cpu_baseline(scenes, actors_cpu, mods, budget_s):
     }
 
 
+def stage_table(eng, fb, actors, reps=20):
+    """Per-stage time (each stage of the forward captured in its own hipGraph, replayed `reps` times between one
+    HIP event pair) next to the stage's ALGORITHMIC flops / bytes of SURVEY.md section 8(d) (fp32, s = 4): what the
+    reference's arithmetic would have to move, not what this build moves (it hoists 2/3 of the Att GEMMs)."""
+    import torch
+    C_, s_ = 128, 4
+    N, A, E = fb.n_nodes, fb.n_actors, sum(fb.n_edges)
+    st, fns = eng.stage_functions(fb, actors)
+    for _, fn in fns:
+        fn()
+    torch.cuda.synchronize()
+    P = [int(p.n_pairs.item()) for p in st["pairs"]]
+    lc_f = 2 * C_ * C_ * (N + E) + 2 * C_ * C_ * N
+    lc_b = s_ * C_ * N + s_ * C_ * E + 8 * E + 16 * s_ * C_ * C_ + s_ * C_ * N + 16 * C_
+    att_f = lambda T, p_: 2 * C_ * C_ * (6 * p_ + 2 * T) + 4 * p_ * C_
+    att_b = lambda T, p_: 2 * s_ * C_ * T + 2 * s_ * C_ * p_ + 24 * p_ + s_ * (8 * C_ * C_ + 10 * C_)
+    alg = {"index": (0.0, 2 * 8 * E * 2 + 8 * (2 * N + 4 * A) + 8 * sum(P)),
+           "map_net": (2 * N * (4 * C_ + 2 * C_ * C_) + 4 * lc_f, 16 * N + s_ * C_ * N + 0.13e6 + 4 * lc_b),
+           "a2m": (2 * N * 132 * C_ + 2 * att_f(N, P[0]), 2 * s_ * C_ * N + 16 * N + 132 * s_ * C_ + 2 * att_b(N, P[0])),
+           "m2m": (4 * lc_f, 4 * lc_b),
+           "m2a": (2 * att_f(A, P[1]), 2 * att_b(A, P[1])),
+           "a2a": (2 * att_f(A, P[2]), 2 * att_b(A, P[2]))}
+    out = {"pairs": {"a2m": P[0], "m2a": P[1], "a2a": P[2]}}
+    side = torch.cuda.Stream()
+    alive = []      # every stage graph stays alive to the end: its private pool holds the tensors the later stages read
+    for name, fn in fns:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            fn()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=side):
+                fn()
+        alive.append(g)
+        torch.cuda.current_stream().wait_stream(side)
+        for _ in range(3):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / reps
+        f, b = alg[name]
+        out[name] = {"us": us, "alg_GFLOP": f / 1e9, "alg_MB": b / 1e6, "TFLOPs": f / us / 1e6, "GBps": b / us / 1e3,
+                     "hbm_frac": b / us / 1e3 / PEAK_HBM_GBPS}
+    return out
+
+
 def laneconv_launch_us(eng, fb, feat_map, feat_m2m, reps=20):
     """Average duration of one fused LaneConv launch without per-launch event overhead: the step's 8 LaneConv
     launches (MapNet's 4 + M2M's 4, their own weights, the batch's CSR plan) captured back-to-back in one
@@ -264,12 +313,14 @@ def main():
             eng.forward(fb, actors, mapnet_only=args.mapnet_only)
     ksum = kt.summary()
     lc_graph_us = None
+    stages_tab = None
     if rank == 0:
         st = eng.forward(fb, actors, stages=not args.mapnet_only, mapnet_only=args.mapnet_only)
         torch.cuda.synchronize()
         assert all(torch.isfinite(v).all() for v in st.values() if torch.is_tensor(v))
         lc_graph_us = laneconv_launch_us(eng, fb, st["nodes"] if args.mapnet_only else st["map_net"],
                                          st["nodes"] if args.mapnet_only else st["a2m"])
+        stages_tab = None if args.mapnet_only or world > 1 else stage_table(eng, fb, actors)
 
     if rank == 0:
         n_scenes = len(scenes)
@@ -327,6 +378,8 @@ def main():
             "kernel_avg_us": {k: float(np.mean(v)) * 1e3 for k, v in ksum.items()},
             "streams": 1 if args.no_graph else args.streams,
         }
+        if stages_tab is not None:
+            line["stages"] = stages_tab
         if single is not None:
             line["single_stream"] = {"value": args.gpus * n_scenes * args.steps / single, "unit": "scenes/s",
                                      "ms_per_step": single / args.steps * 1e3}

@@ -107,6 +107,19 @@ int lgcn_pairs_build(const float *agt_ctrs, const int32_t *agt_off,
                      int32_t *n_pairs, int32_t *rowptr, int32_t *ws,
                      void *stream);
 
+/* Several pair searches in the SAME three launches (the forward needs three: A2M, M2A, A2A; each saves the
+ * launch boundaries of the others).  `jobs` is a HOST array of n_jobs <= 4 entries; fields as in lgcn_pairs_build. */
+typedef struct {
+    const float *agt_ctrs; const int32_t *agt_off;
+    const float *ctx_ctrs; const int32_t *ctx_off;
+    int32_t n_scenes; int32_t legacy_offsets;
+    int64_t n_agt, n_ctx;
+    float dist_th; int32_t pad_;
+    int32_t *hi, *wi; int64_t cap;
+    int32_t *n_pairs, *rowptr, *ws;
+} lgcn_pairs_job_t;
+int lgcn_pairs_build_multi(const lgcn_pairs_job_t *jobs, int n_jobs, void *stream);
+
 /* int32 -> int64 widening of the first *n (device count, clamped to cap)
  * entries; the tail is left untouched.  Used to hand hi/wi back as the
  * reference's LongTensors. */

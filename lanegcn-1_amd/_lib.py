@@ -20,6 +20,16 @@ class Rel(C.Structure):
     _fields_ = [("src", C.c_void_p), ("wp", C.c_void_p), ("mode", C.c_int32), ("ridx", C.c_int32)]
 
 
+class PairsJob(C.Structure):      # lgcn_pairs_job_t
+    _fields_ = [
+        ("agt_ctrs", C.c_void_p), ("agt_off", C.c_void_p), ("ctx_ctrs", C.c_void_p), ("ctx_off", C.c_void_p),
+        ("n_scenes", C.c_int32), ("legacy_offsets", C.c_int32), ("n_agt", C.c_int64), ("n_ctx", C.c_int64),
+        ("dist_th", C.c_float), ("pad_", C.c_int32),
+        ("hi", C.c_void_p), ("wi", C.c_void_p), ("cap", C.c_int64),
+        ("n_pairs", C.c_void_p), ("rowptr", C.c_void_p), ("ws", C.c_void_p),
+    ]
+
+
 class AggMlp(C.Structure):
     _fields_ = [
         ("n_rows", C.c_int64), ("n_rel", C.c_int32), ("n_rel_csr", C.c_int32),
@@ -46,6 +56,7 @@ SIGNATURES = {
     "lgcn_csr_build": (C.c_int, [_P, _P, _P, _I, _L, _P, _P, _P, _P]),
     "lgcn_pairs_ws_elems": (C.c_int64, [_L, _I]),
     "lgcn_pairs_build": (C.c_int, [_P, _P, _P, _P, _I, _L, _L, _F, _I, _P, _P, _L, _P, _P, _P, _P]),
+    "lgcn_pairs_build_multi": (C.c_int, [_P, _I, _P]),
     "lgcn_widen_i32": (C.c_int, [_P, _P, _L, _P, _P]),
     "lgcn_packed_bytes": (C.c_int64, [_I, _I]),
     "lgcn_pack_weight": (C.c_int, [_P, _I, _I, _I, _I, _P, _P]),

@@ -190,13 +190,13 @@ __device__ __forceinline__ bool within(float ax, float ay, float cx, float cy, f
 // advances the numbering owns h = hval(g), so rowptr_q[hval(g)] = rowptr[g]; rows of scenes that do not advance
 // it (legacy: scenes without pairs) fill the tail [h_used, T), where no pair can follow: P.  rowptr_q[T] = P.
 template <int PASS>
-__global__ __launch_bounds__(256) void k_pairs_rows(const float2 *agt, const int32_t *agt_off,
-                                                    const float2 *ctx, const int32_t *ctx_off,
-                                                    int n_scenes, int n_agt, float th,
-                                                    int32_t *rowcnt, const int32_t *rowptr,
-                                                    const int32_t *hi_base, const int32_t *wi_base,
-                                                    int32_t *hi, int32_t *wi, int64_t cap, int legacy,
-                                                    int32_t *rowptr_q) {
+__device__ __forceinline__ void pairs_rows_body(const float2 *agt, const int32_t *agt_off,
+                                                const float2 *ctx, const int32_t *ctx_off,
+                                                int n_scenes, int n_agt, float th,
+                                                int32_t *rowcnt, const int32_t *rowptr,
+                                                const int32_t *hi_base, const int32_t *wi_base,
+                                                int32_t *hi, int32_t *wi, int64_t cap, int legacy,
+                                                int32_t *rowptr_q) {
     const int lane = threadIdx.x & 63;
     const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_agt) return;
@@ -239,13 +239,36 @@ __global__ __launch_bounds__(256) void k_pairs_rows(const float2 *agt, const int
     if (PASS == 0 && lane == 0) rowcnt[g] = count;
 }
 
+// Workspace layout of one pair search: rowptr_true [T+1] | hi_base [B+1] | wi_base [B]
+struct PairsJob {
+    const float2 *agt; const int32_t *agt_off;
+    const float2 *ctx; const int32_t *ctx_off;
+    int n_scenes, n_agt, legacy;
+    float th;
+    int32_t *hi, *wi;
+    int64_t cap;
+    int32_t *n_pairs, *rowptr_q, *ws;
+    __device__ int32_t *rp() const { return ws; }
+    __device__ int32_t *hi_base() const { return ws + (n_agt + 1); }
+    __device__ int32_t *wi_base() const { return ws + (n_agt + 1) + n_scenes + 1; }
+};
+struct PairsJobs { PairsJob j[4]; };
+
+// blockIdx.y selects the job; blocks past a job's rows return at once
+template <int PASS>
+__global__ __launch_bounds__(256) void k_pairs_rows(const PairsJobs jobs) {
+    const PairsJob &j = jobs.j[blockIdx.y];
+    pairs_rows_body<PASS>(j.agt, j.agt_off, j.ctx, j.ctx_off, j.n_scenes, j.n_agt, j.th, j.rp(), j.rp(), j.hi_base(),
+                          j.wi_base(), j.hi, j.wi, j.cap, j.legacy, j.rowptr_q);
+}
+
 // Single block: exclusive scan of the row counts in place (rp[0..T), rp[T] = P; each thread owns a contiguous
 // run), then the per-scene index bases (lanegcn.py:681-687; legacy: a scene without pairs does not advance the
 // running counts), hi_base[n_scenes] = rows numbered in all (h_used), and P.  The pair search has at most a few
 // 10^4 rows, so one block replaces four launches.
-__global__ __launch_bounds__(1024) void k_pairs_scan_bases(int32_t *rp, int n_agt, const int32_t *agt_off,
-                                                           const int32_t *ctx_off, int n_scenes, int legacy, int64_t cap,
-                                                           int32_t *hi_base, int32_t *wi_base, int32_t *n_pairs) {
+__device__ __forceinline__ void pairs_scan_bases_body(int32_t *rp, int n_agt, const int32_t *agt_off,
+                                                      const int32_t *ctx_off, int n_scenes, int legacy, int64_t cap,
+                                                      int32_t *hi_base, int32_t *wi_base, int32_t *n_pairs) {
     __shared__ int lds[1024 / 64 + 1];
     const int per = (n_agt + 1024) / 1024;                  // ceil((T + 1) / 1024)
     const int64_t b = (int64_t)threadIdx.x * per;
@@ -279,6 +302,21 @@ __global__ __launch_bounds__(1024) void k_pairs_scan_bases(int32_t *rp, int n_ag
     if (threadIdx.x == 0) {
         hi_base[n_scenes] = carry_h;
         *n_pairs = (int64_t)tot > cap ? -tot : tot;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_pairs_scan_bases(const PairsJobs jobs) {    // one block per job
+    const PairsJob &j = jobs.j[blockIdx.x];
+    pairs_scan_bases_body(j.rp(), j.n_agt, j.agt_off, j.ctx_off, j.n_scenes, j.legacy, j.cap, j.hi_base(), j.wi_base(),
+                          j.n_pairs);
+    if (j.n_agt == 0 && threadIdx.x == 0) j.rowptr_q[0] = 0;     // no rows: the fill pass never runs for this job
+}
+
+// rowptr and cursor of the CSR plan zeroed in one launch (two memset nodes cost a launch boundary each)
+__global__ __launch_bounds__(256) void k_zero2(int32_t *a, int32_t *b, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        a[i] = 0;
+        b[i] = 0;
     }
 }
 
@@ -360,10 +398,7 @@ int lgcn_csr_build(const int64_t *const *u_host, const int64_t *const *v_host, c
     const int64_t nk1 = lgcn_csr_rowptr_elems(n_nodes, n_rel);  // keys + 1
     int32_t *cursor = ws;
     int32_t *sums = ws + nk1;
-    hipError_t e = hipMemsetAsync(rowptr, 0, nk1 * sizeof(int32_t), st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(cursor, 0, nk1 * sizeof(int32_t), st);
-    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(k_zero2, dim3(grid_for(nk1, 256, 1024)), dim3(256), 0, st, rowptr, cursor, nk1);
     if (total > 0) {
         hipLaunchKernelGGL((k_csr_edges<0>), dim3(grid_for(total, 256)), dim3(256), 0, st, t, rowptr, nullptr, nullptr);
     }
@@ -383,40 +418,53 @@ int64_t lgcn_pairs_ws_elems(int64_t n_agt, int n_scenes) {
     return (n_agt + 1) + 2 * (int64_t)n_scenes + 1;
 }
 
+static int pairs_job_check(const lgcn_pairs_job_t &q) {
+    if (q.n_scenes < 1 || q.n_agt < 0 || q.n_ctx < 0 || q.cap < 0) return LGCN_EINVAL;
+    if (q.n_agt > 0x7ffffff0 || q.n_ctx > 0x7ffffff0 || q.cap > 0x7ffffff0) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(q.agt_off); LGCN_CHECK_PTR(q.ctx_off); LGCN_CHECK_PTR(q.n_pairs);
+    LGCN_CHECK_PTR(q.rowptr); LGCN_CHECK_PTR(q.ws);
+    if (q.n_agt > 0) LGCN_CHECK_PTR(q.agt_ctrs);
+    if (q.n_ctx > 0) LGCN_CHECK_PTR(q.ctx_ctrs);
+    if (q.cap > 0) { LGCN_CHECK_PTR(q.hi); LGCN_CHECK_PTR(q.wi); }
+    return LGCN_OK;
+}
+
+int lgcn_pairs_build_multi(const lgcn_pairs_job_t *jobs, int n_jobs, void *stream) {
+    if (n_jobs < 1 || n_jobs > 4) return LGCN_EINVAL;
+    LGCN_CHECK_PTR(jobs);
+    hipStream_t st = (hipStream_t)stream;
+    PairsJobs dj;
+    int64_t max_rows = 0;
+    for (int k = 0; k < n_jobs; ++k) {
+        const lgcn_pairs_job_t &q = jobs[k];
+        const int rc = pairs_job_check(q);
+        if (rc != LGCN_OK) return rc;
+        PairsJob &d = dj.j[k];
+        d.agt = (const float2 *)q.agt_ctrs; d.agt_off = q.agt_off;
+        d.ctx = (const float2 *)q.ctx_ctrs; d.ctx_off = q.ctx_off;
+        d.n_scenes = q.n_scenes; d.n_agt = (int)q.n_agt; d.legacy = q.legacy_offsets; d.th = q.dist_th;
+        d.hi = q.hi; d.wi = q.wi; d.cap = q.cap; d.n_pairs = q.n_pairs; d.rowptr_q = q.rowptr; d.ws = q.ws;
+        if (q.n_agt > max_rows) max_rows = q.n_agt;
+    }
+    for (int k = n_jobs; k < 4; ++k) dj.j[k] = dj.j[0];
+    // three launches for all jobs: count per target row, scan + per-scene bases (one block per job), fill
+    // (+ segment table).  A job without rows still gets rowptr[0] = P = 0 from the scan block.
+    const unsigned row_blocks = (unsigned)((max_rows + 3) / 4);
+    if (max_rows > 0) hipLaunchKernelGGL((k_pairs_rows<0>), dim3(row_blocks, n_jobs), dim3(256), 0, st, dj);
+    hipLaunchKernelGGL(k_pairs_scan_bases, dim3(n_jobs), dim3(1024), 0, st, dj);
+    if (max_rows > 0) hipLaunchKernelGGL((k_pairs_rows<1>), dim3(row_blocks, n_jobs), dim3(256), 0, st, dj);
+    return launch_status();
+}
+
 int lgcn_pairs_build(const float *agt_ctrs, const int32_t *agt_off, const float *ctx_ctrs,
                      const int32_t *ctx_off, int n_scenes, int64_t n_agt, int64_t n_ctx, float dist_th,
                      int legacy_offsets, int32_t *hi, int32_t *wi, int64_t cap, int32_t *n_pairs,
                      int32_t *rowptr, int32_t *ws, void *stream) {
-    if (n_scenes < 1 || n_agt < 0 || n_ctx < 0 || cap < 0) return LGCN_EINVAL;
-    if (n_agt > 0x7ffffff0 || n_ctx > 0x7ffffff0 || cap > 0x7ffffff0) return LGCN_ESHAPE;
-    LGCN_CHECK_PTR(agt_off); LGCN_CHECK_PTR(ctx_off); LGCN_CHECK_PTR(n_pairs);
-    LGCN_CHECK_PTR(rowptr); LGCN_CHECK_PTR(ws);
-    if (n_agt > 0) LGCN_CHECK_PTR(agt_ctrs);
-    if (n_ctx > 0) LGCN_CHECK_PTR(ctx_ctrs);
-    if (cap > 0) { LGCN_CHECK_PTR(hi); LGCN_CHECK_PTR(wi); }
-    hipStream_t st = (hipStream_t)stream;
-    const int T = (int)n_agt;
-    int32_t *rp_true = ws;
-    int32_t *hi_base = rp_true + (T + 1);
-    int32_t *wi_base = hi_base + n_scenes + 1;
-    // three launches: count per target row, scan + per-scene bases (one block), fill (+ segment table)
-    const unsigned row_blocks = (unsigned)((T + 3) / 4);
-    if (T > 0) {
-        hipLaunchKernelGGL((k_pairs_rows<0>), dim3(row_blocks), dim3(256), 0, st,
-                           (const float2 *)agt_ctrs, agt_off, (const float2 *)ctx_ctrs, ctx_off, n_scenes, T,
-                           dist_th, rp_true, nullptr, nullptr, nullptr, nullptr, nullptr, (int64_t)0, 0, nullptr);
-    }
-    hipLaunchKernelGGL(k_pairs_scan_bases, dim3(1), dim3(1024), 0, st, rp_true, T, agt_off, ctx_off, n_scenes,
-                       legacy_offsets, cap, hi_base, wi_base, n_pairs);
-    if (T > 0) {
-        hipLaunchKernelGGL((k_pairs_rows<1>), dim3(row_blocks), dim3(256), 0, st,
-                           (const float2 *)agt_ctrs, agt_off, (const float2 *)ctx_ctrs, ctx_off, n_scenes, T,
-                           dist_th, nullptr, rp_true, hi_base, wi_base, hi, wi, cap, legacy_offsets, rowptr);
-    } else {
-        hipError_t e = hipMemsetAsync(rowptr, 0, sizeof(int32_t), st);    // rowptr_q[0] = P = 0
-        if (e != hipSuccess) return (int)e;
-    }
-    return launch_status();
+    lgcn_pairs_job_t q;
+    q.agt_ctrs = agt_ctrs; q.agt_off = agt_off; q.ctx_ctrs = ctx_ctrs; q.ctx_off = ctx_off;
+    q.n_scenes = n_scenes; q.legacy_offsets = legacy_offsets; q.n_agt = n_agt; q.n_ctx = n_ctx;
+    q.dist_th = dist_th; q.pad_ = 0; q.hi = hi; q.wi = wi; q.cap = cap; q.n_pairs = n_pairs; q.rowptr = rowptr; q.ws = ws;
+    return lgcn_pairs_build_multi(&q, 1, stream);
 }
 
 int lgcn_widen_i32(const int32_t *in, const int32_t *n_dev, int64_t cap, int64_t *out, void *stream) {

@@ -155,7 +155,7 @@ class HotPathEngine:
         if side is not None:
             side.wait_stream(main)
         with torch.cuda.stream(side if side is not None else main):
-            pairs = [ops.pairs_build(*s, self.legacy_offsets, bufs=b) for s, b in zip(searches, bufs)]
+            pairs = ops.pairs_build_multi(searches, self.legacy_offsets, bufs=bufs)   # three sets, three launches
         # graph_gather (lanegcn.py:171-209) + CSR plan
         g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
         us = [g64[a:b] for (a, b), _ in fb.rel_slices]
@@ -192,6 +192,49 @@ class HotPathEngine:
         out["nodes"], out["actors"] = feat, act
         out["n_pairs"] = [p.n_pairs for p in pairs]
         return out
+
+    @torch.no_grad()
+    def stage_functions(self, fb: FlatBatch, actors: torch.Tensor):
+        """The same forward cut at the reference's module boundaries, for per-stage measurement: returns
+        (state, [(name, fn)]); fn() runs one stage on the tensors the previous stages left in `state`
+        (run them in order once before capturing any of them in a graph)."""
+        cfg, st = self.config, {}
+
+        def index():
+            searches = ((fb.node_ctrs, fb.node_off, fb.actor_ctrs, fb.actor_off, cfg["actor2map_dist"], fb.cap_a2m),
+                        (fb.actor_ctrs, fb.actor_off, fb.node_ctrs, fb.node_off, cfg["map2actor_dist"], fb.cap_a2m),
+                        (fb.actor_ctrs, fb.actor_off, fb.actor_ctrs, fb.actor_off, cfg["actor2actor_dist"], fb.cap_a2a))
+            st["pairs"] = ops.pairs_build_multi(searches, self.legacy_offsets)
+            g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
+            st["plan"] = ops.csr_build([g64[a:b] for (a, b), _ in fb.rel_slices],
+                                       [g64[a:b] for _, (a, b) in fb.rel_slices], fb.n_nodes)
+
+        def map_net():
+            st["nodes"] = M.lane_conv(self.map_net.fuse, self.map_net.stem(fb.node_ctrs, fb.node_feats), st["plan"],
+                                      fb.num_scales)
+
+        def a2m():
+            feat = self.a2m.fuse_meta(st["nodes"], fb.turn, fb.control, fb.intersect)
+            for att in self.a2m.att:
+                feat = att.run(feat, actors, st["pairs"][0])
+            st["nodes_a2m"] = feat
+
+        def m2m():
+            st["nodes_m2m"] = M.lane_conv(self.m2m.fuse, st["nodes_a2m"], st["plan"], fb.num_scales)
+
+        def m2a():
+            act = actors
+            for att in self.m2a.att:
+                act = att.run(act, st["nodes_m2m"], st["pairs"][1])
+            st["actors_m2a"] = act
+
+        def a2a():
+            act = st["actors_m2a"]
+            for att in self.a2a.att:
+                act = att.run(act, act, st["pairs"][2])
+            st["actors_a2a"] = act
+
+        return st, [("index", index), ("map_net", map_net), ("a2m", a2m), ("m2m", m2m), ("m2a", m2a), ("a2a", a2a)]
 
     def capture(self, fb: FlatBatch, actors: torch.Tensor, warmup: int = 2, **fwd_kw):
         """Capture one forward into a hipGraph.  Returns (graph, outputs); ``graph.replay()`` re-runs

@@ -203,6 +203,36 @@ def pairs_build(agt_ctrs: torch.Tensor, agt_off: torch.Tensor, ctx_ctrs: torch.T
     return PairSet(hi, wi, n_pairs, rowptr, cap, T, agt_ctrs, ctx_ctrs)
 
 
+def pairs_build_multi(searches, legacy_offsets: bool = True, bufs=None) -> List["PairSet"]:
+    """Up to four pair searches in the same three launches (the forward's A2M, M2A and A2A sets).  `searches`:
+    tuples (agt_ctrs, agt_off, ctx_ctrs, ctx_off, dist_th, cap) as for pairs_build; `bufs`: pairs_alloc() per search."""
+    lib = L.load()
+    n = len(searches)
+    if n < 1 or n > 4:
+        raise L.LgcnError("pairs_build_multi: 1..4 searches")
+    jobs = (L.PairsJob * n)()
+    out, keep = [], []
+    for k, (agt_ctrs, agt_off, ctx_ctrs, ctx_off, dist_th, cap) in enumerate(searches):
+        agt_ctrs = _dev(agt_ctrs, torch.float32, "agt_ctrs")
+        ctx_ctrs = _dev(ctx_ctrs, torch.float32, "ctx_ctrs")
+        agt_off = _dev(agt_off, torch.int32, "agt_off")
+        ctx_off = _dev(ctx_off, torch.int32, "ctx_off")
+        B = agt_off.numel() - 1
+        if ctx_off.numel() != B + 1 or B < 1:
+            raise L.LgcnError("pairs_build_multi: offset tables must both have B+1 entries")
+        T, S = agt_ctrs.shape[0], ctx_ctrs.shape[0]
+        hi, wi, n_pairs, rowptr, ws = bufs[k] if bufs is not None else pairs_alloc(T, B, cap, agt_ctrs.device)
+        j = jobs[k]
+        j.agt_ctrs, j.agt_off, j.ctx_ctrs, j.ctx_off = agt_ctrs.data_ptr(), agt_off.data_ptr(), ctx_ctrs.data_ptr(), ctx_off.data_ptr()
+        j.n_scenes, j.legacy_offsets, j.n_agt, j.n_ctx, j.dist_th = B, int(bool(legacy_offsets)), T, S, float(dist_th)
+        j.hi, j.wi, j.cap = hi.data_ptr(), wi.data_ptr(), cap
+        j.n_pairs, j.rowptr, j.ws = n_pairs.data_ptr(), rowptr.data_ptr(), ws.data_ptr()
+        keep += [agt_ctrs, ctx_ctrs, agt_off, ctx_off, ws]    # ws must outlive the launch below (nothing else holds it)
+        out.append(PairSet(hi, wi, n_pairs, rowptr, cap, T, agt_ctrs, ctx_ctrs))
+    L.check(lib.lgcn_pairs_build_multi(jobs, n, _stream()), "lgcn_pairs_build_multi")
+    return out
+
+
 # ------------------------------------------------------------------ weight packing
 def _cached(weight: torch.Tensor, key, make):
     """Per-tensor-object cache, valid while (data_ptr, _version) are unchanged.  Living on the

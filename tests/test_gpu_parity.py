@@ -501,3 +501,27 @@ def test_laneconv_on_a_multigraph_vs_oracle(hip, ref_state_names):
             got = M.lane_conv(m2m.fuse, feat.cuda(), plan, 6, tile_rb=rb).cpu().numpy()
             err = float(np.abs(got - want).max())
             assert err <= FTOL, (rb, err)
+
+
+def test_pairs_build_multi_equals_single_searches(hip):
+    """The three pair sets of a forward in one launch triple must be bit-identical to three single searches
+    (legacy and fixed offsets; a scene without pairs; different T / S / thresholds per job)."""
+    M, ops = hip
+    rng = np.random.default_rng(23)
+    na, nc = (70, 3, 130, 1), (65, 4, 200, 2)
+    agt = torch.cat([torch.from_numpy(rng.integers(-6, 7, (n, 2)).astype(np.float32)) for n in na]).cuda()
+    ctx = torch.cat([torch.from_numpy(rng.integers(-6, 7, (n, 2)).astype(np.float32)) + (500.0 if i == 1 else 0.0)
+                     for i, n in enumerate(nc)]).cuda()
+    a_off = torch.tensor(np.concatenate([[0], np.cumsum(na)]), dtype=torch.int32).cuda()
+    c_off = torch.tensor(np.concatenate([[0], np.cumsum(nc)]), dtype=torch.int32).cuda()
+    cap_ac = int(np.dot(na, nc))
+    searches = [(agt, a_off, ctx, c_off, 5.0, cap_ac), (ctx, c_off, agt, a_off, 3.0, cap_ac),
+                (agt, a_off, agt, a_off, 100.0, int(np.dot(na, na)))]
+    for legacy in (True, False):
+        multi = ops.pairs_build_multi(searches, legacy)
+        for s, pm in zip(searches, multi):
+            ps = ops.pairs_build(*s, legacy)
+            P = ps.count()
+            assert pm.count() == P and P > 0
+            assert torch.equal(pm.hi[:P], ps.hi[:P]) and torch.equal(pm.wi[:P], ps.wi[:P])
+            assert torch.equal(pm.rowptr, ps.rowptr)
