@@ -8,8 +8,8 @@
 namespace lgcn {
 
 // ---------------------------------------------------------------- scan ----
-// Exclusive scan of int32, three launches: per-block scan + block totals,
-// scan of the totals (single block, looping), add-back.
+// Exclusive scan of int32: per-block scan + block totals, then an add-back in which every block sums the totals
+// before it (two launches; beyond 4096 blocks the totals are scanned by their own single-block launch first).
 constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;
@@ -77,6 +77,20 @@ __global__ __launch_bounds__(1024) void k_scan_sums(int32_t *sums, int nb) {
     }
 }
 
+// Add-back with the scan of the block totals folded in: block b sums the totals of the blocks before it (a few
+// hundred at most at the plan's sizes) instead of waiting for a separate single-block scan launch.
+__global__ __launch_bounds__(kScanThreads) void k_scan_add_prefix(int32_t *out, const int32_t *sums, int64_t n) {
+    __shared__ int lds[kScanThreads / 64 + 1];
+    int part = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += kScanThreads) part += sums[i];
+    int add;
+    block_exclusive_scan<kScanThreads>(part, &add, lds);
+    const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+    for (int i = 0; i < kScanItems; ++i)
+        if (base + i < n) out[base + i] += add;
+}
+
 __global__ __launch_bounds__(kScanThreads) void k_scan_add(int32_t *out, const int32_t *sums, int64_t n) {
     const int add = sums[blockIdx.x];
     const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
@@ -93,9 +107,11 @@ static int exclusive_scan(const int32_t *in, int32_t *out, int64_t n, int32_t *s
     const int64_t nb = (n + kScanTile - 1) / kScanTile;
     if (nb > 0x7fffffff) return LGCN_ESHAPE;
     hipLaunchKernelGGL(k_scan_blocks, dim3((unsigned)nb), dim3(kScanThreads), 0, st, in, out, sums, n);
-    if (nb > 1) {
+    if (nb > 4096) {          // very long inputs: scan the block totals in their own launch
         hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, st, sums, (int)nb);
         hipLaunchKernelGGL(k_scan_add, dim3((unsigned)nb), dim3(kScanThreads), 0, st, out, sums, n);
+    } else if (nb > 1) {
+        hipLaunchKernelGGL(k_scan_add_prefix, dim3((unsigned)nb), dim3(kScanThreads), 0, st, out, sums, n);
     }
     return launch_status();
 }
