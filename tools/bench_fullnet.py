@@ -21,7 +21,6 @@ from lanegcn_amd.engine import FullNetEngine, collate_flat  # noqa: E402
 def main():
     phase = sys.argv[1] if len(sys.argv) > 1 else "eager"      # eager | graph1 | graph4  (one phase per process)
     torch.manual_seed(0)
-    torch.backends.cudnn.benchmark = os.environ.get("LGCN_MIOPEN_BENCH", "0") == "1"
     net = M.Net(M.config).cuda().eval()
     res = {}
     scenes = gen.synth_batch("S2", seed=3)
