@@ -308,6 +308,16 @@ int lgcn_gn_fwd(const float *x, const float *gamma, const float *beta, const flo
                 int64_t n_rows, float eps, int relu, float *out, void *stream);
 
 /*
+ * GroupNorm with ONE group over the C x L elements of every item of x [n_items, C, L] (contiguous: channel
+ * c = element / L), per-channel gamma / beta, then optional "+ res" (same shape) and ReLU, in one launch:
+ *   out = [ReLU]( (x - mean_item) * rstd_item * gamma[c] + beta[c] [+ res] )
+ * This is ActorNet's Conv1d / Res1d norm (reference layers.py:40-62, 142-190 with ng = 1; biased variance,
+ * two-pass), which stock ATen runs as three to five launches per call.  C * L <= 16384.
+ */
+int lgcn_gn_cl(const float *x, int64_t n_items, int C, int L, const float *gamma, const float *beta,
+               float eps, const float *res, int relu, float *out, void *stream);
+
+/*
  * out[n] = sum_{j in [rowptr[n], rowptr[n+1])} src[col ? col[j] : j]   for n < n_rows (rows of 128 floats,
  * fixed summation order).  col == NULL: contiguous segments (index_add_ by a sorted index, lanegcn.py:703);
  * with col: a plain CSR (transposes of gathers in the backward).

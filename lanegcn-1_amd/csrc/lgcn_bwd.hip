@@ -138,6 +138,40 @@ __global__ __launch_bounds__(256) void k_gn_fwd(const float *__restrict__ x, con
     if (live) row_store_global(out + n * kC, t, r);
 }
 
+// One wave per item of x [n, C, L]: GroupNorm over the item's C * L elements (two-pass mean / biased variance),
+// per-channel affine, optional residual and ReLU.  The item is a few KB (640 .. 2,560 floats in ActorNet) and is
+// re-read from cache for the second and third sweep.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_gn_cl(const float *__restrict__ x, int64_t n_items, int C, int L,
+                                               const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
+                                               const float *__restrict__ res, int relu, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const int n = C * L;
+    const float *xi = x + item * n;
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += xi[i];
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+    for (int i = lane; i < n; i += 64) { const float d = xi[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + eps);
+    const float *ri = res ? res + item * n : nullptr;
+    float *oi = out + item * n;
+    for (int i = lane; i < n; i += 64) {
+        const int c = i / L;
+        float v = (xi[i] - mean) * rstd * gamma[c] + beta[c];
+        if (ri) v += ri[i];
+        if (relu) v = fmaxf(v, 0.f);
+        oi[i] = v;
+    }
+}
+
 // one half-wave per output row, float4 per lane
 __global__ __launch_bounds__(256) void k_gather_sum(const float4 *__restrict__ src, const int32_t *__restrict__ rowptr,
                                                     const int32_t *__restrict__ col, int64_t n_rows,
@@ -206,6 +240,17 @@ int lgcn_gn_fwd(const float *x, const float *gamma, const float *beta, const flo
     if (res) LGCN_CHECK_ALIGN16(res);
     hipLaunchKernelGGL(k_gn_fwd, dim3((unsigned)((n_rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
                        res, n_rows, eps, relu, out);
+    return launch_status();
+}
+
+int lgcn_gn_cl(const float *x, int64_t n_items, int C, int L, const float *gamma, const float *beta, float eps,
+               const float *res, int relu, float *out, void *stream) {
+    if (n_items < 0 || C < 1 || L < 1 || (int64_t)C * L > 16384) return LGCN_EINVAL;
+    if (n_items == 0) return LGCN_OK;
+    if (n_items > 0x7fffffff) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(x); LGCN_CHECK_PTR(gamma); LGCN_CHECK_PTR(beta); LGCN_CHECK_PTR(out);
+    hipLaunchKernelGGL(k_gn_cl, dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n_items, C, L,
+                       gamma, beta, eps, res, relu, out);
     return launch_status();
 }
 

@@ -24,16 +24,27 @@ def _norm(norm, ng, n_out, dims):
     raise SystemExit("SyncBN has not been added!")
 
 
-def group_norm1(x, norm, relu=False):
-    """Apply `norm` so that its backward is correct on this stack.
+def group_norm1(x, norm, relu=False, res=None):
+    """out = [ReLU](norm(x) [+ res]).  Apply `norm` so that its backward is correct on this stack, and in one launch
+    where no gradient is needed: [n, C, L] inputs under GroupNorm(1 group) run on lgcn_gn_cl (stock ATen: three
+    launches for the norm plus one each for the residual add and the ReLU).
 
     Stock PyTorch-ROCm 2.10.0+rocm7.0 returns wrong dgamma / dbeta from GroupNorm's backward on the GPU once
     the batch dimension exceeds ~128 (2-D and 3-D inputs alike; forward and dx are right) -- measured with
     tools/check_aten_gn.py.  When gradients are needed on a CUDA tensor, GroupNorm(1 group) therefore runs on
     the HIP row kernels ([rows,128] inputs) or on an explicit mean/var formula made of basic ops."""
     if (not isinstance(norm, nn.GroupNorm) or norm.num_groups != 1 or not x.is_cuda
-            or not ops.wants_grad(x, norm.weight, norm.bias)):
+            or not ops.wants_grad(x, norm.weight, norm.bias, res)):
+        if (isinstance(norm, nn.GroupNorm) and norm.num_groups == 1 and x.is_cuda and x.dim() == 3
+                and x.dtype == torch.float32 and x.shape[1] * x.shape[2] <= 16384 and x.shape[0] > 0):
+            return ops.gn_cl(x.contiguous(), norm.weight, norm.bias, norm.eps, res=None if res is None else res.contiguous(),
+                             relu=relu)
         out = norm(x)
+        if res is not None:
+            out = out + res
+        return F.relu(out) if relu else out
+    if res is not None:
+        out = group_norm1(x, norm) + res
         return F.relu(out) if relu else out
     if x.dim() == 2 and x.shape[1] == ops.C_FEAT:
         from . import autograd as A
@@ -109,11 +120,9 @@ class Res1d(nn.Module):
 
     def forward(self, x):
         out = group_norm1(self.conv1(x), self.bn1, relu=True)
-        out = group_norm1(self.conv2(out), self.bn2)
         if self.downsample is not None:
             x = group_norm1(self.downsample[0](x), self.downsample[1])
-        out = out + x
-        return F.relu(out) if self.act else out
+        return group_norm1(self.conv2(out), self.bn2, relu=self.act, res=x)     # norm + residual + ReLU: one launch
 
 
 class LinearRes(nn.Module):

@@ -503,6 +503,22 @@ def gn_fwd(x, gn=None, res=None, relu=False, eps=EPS):
     return out
 
 
+def gn_cl(x, gamma, beta, eps=EPS, res=None, relu=False):
+    """out = [ReLU](GroupNorm(1 group over (C, L))(x) [+ res]) for x [n, C, L]: ActorNet's conv norms in one launch."""
+    lib = L.load()
+    x = _dev(x, torch.float32, "x")
+    if x.dim() != 3:
+        raise L.LgcnError("gn_cl: x must be [n, C, L]")
+    res = None if res is None else _dev(res, torch.float32, "res")
+    if res is not None and res.shape != x.shape:
+        raise L.LgcnError("gn_cl: res must have the shape of x")
+    out = torch.empty_like(x)
+    gamma, beta = _dev(gamma.detach(), torch.float32, "gamma"), _dev(beta.detach(), torch.float32, "beta")
+    L.check(lib.lgcn_gn_cl(_ptr(x), x.shape[0], x.shape[1], x.shape[2], _ptr(gamma), _ptr(beta), float(eps), _ptr(res),
+                           int(bool(relu)), _ptr(out), _stream()), "lgcn_gn_cl")
+    return out
+
+
 def gn_bwd(dy, x, post, gamma, eps=EPS, want_g=False):
     """Backward of out = [ReLU](GN(x) [+res]): returns (dx, g, dgamma, dbeta); g = dy masked by post > 0
     (the gradient into `res`), None unless want_g.  gamma None: mask only."""

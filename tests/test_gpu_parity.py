@@ -525,3 +525,24 @@ def test_pairs_build_multi_equals_single_searches(hip):
             assert pm.count() == P and P > 0
             assert torch.equal(pm.hi[:P], ps.hi[:P]) and torch.equal(pm.wi[:P], ps.wi[:P])
             assert torch.equal(pm.rowptr, ps.rowptr)
+
+
+@pytest.mark.parametrize("shape", [(1600, 32, 20), (37, 64, 10), (5, 128, 5), (130, 128, 20), (3, 7, 3)])
+def test_gn_cl_vs_torch_group_norm(hip, shape):
+    """lgcn_gn_cl = GroupNorm(1 group over (C, L)) [+ res] [ReLU] in one launch vs torch's fp64 GroupNorm on the CPU."""
+    M, ops = hip
+    torch.manual_seed(shape[0])
+    n, C_, L_ = shape
+    x = torch.randn(n, C_, L_) * 3.0 + 0.7
+    res = torch.randn(n, C_, L_)
+    gn = torch.nn.GroupNorm(1, C_)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+    ref = torch.nn.functional.group_norm(x.double(), 1, gn.weight.double(), gn.bias.double(), gn.eps)
+    for use_res in (False, True):
+        for relu in (False, True):
+            want = ref + res.double() if use_res else ref
+            want = want.relu() if relu else want
+            got = ops.gn_cl(x.cuda(), gn.weight.cuda(), gn.bias.cuda(), gn.eps, res=res.cuda() if use_res else None, relu=relu)
+            assert float((got.cpu().double() - want).abs().max()) <= 2e-5, (use_res, relu)
