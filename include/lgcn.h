@@ -313,9 +313,12 @@ int lgcn_gn_fwd(const float *x, const float *gamma, const float *beta, const flo
  *   out = [ReLU]( (x - mean_item) * rstd_item * gamma[c] + beta[c] [+ res] )
  * This is ActorNet's Conv1d / Res1d norm (reference layers.py:40-62, 142-190 with ng = 1; biased variance,
  * two-pass), which stock ATen runs as three to five launches per call.  C * L <= 16384.
+ * res_up2 != 0: res is [n_items, C, L/2] (L even) and is upsampled x2 on the fly (linear, align_corners = False:
+ * res'[2i] = 0.25 r[i-1] + 0.75 r[i], res'[2i+1] = 0.75 r[i] + 0.25 r[i+1], edges clamped) -- the top-down step of
+ * the FPN, "interpolate(out, scale_factor=2, mode='linear') + lateral(x)", reference lanegcn.py:256-260.
  */
 int lgcn_gn_cl(const float *x, int64_t n_items, int C, int L, const float *gamma, const float *beta,
-               float eps, const float *res, int relu, float *out, void *stream);
+               float eps, const float *res, int res_up2, int relu, float *out, void *stream);
 
 /*
  * out[n] = sum_{j in [rowptr[n], rowptr[n+1])} src[col ? col[j] : j]   for n < n_rows (rows of 128 floats,

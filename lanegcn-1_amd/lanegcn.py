@@ -509,7 +509,15 @@ class ActorNet(nn.Module):
             pyramid.append(out)
         out = self.lateral[-1](pyramid[-1])
         for i in range(len(pyramid) - 2, -1, -1):
-            out = upsample2_linear(out) + self.lateral[i](pyramid[i])
+            lat = self.lateral[i]
+            if (out.is_cuda and not ops.wants_grad(out, pyramid[i], *ops.module_params(lat))
+                    and isinstance(lat.norm, nn.GroupNorm) and lat.norm.num_groups == 1 and not lat.act
+                    and pyramid[i].shape[2] == 2 * out.shape[2]):
+                # lateral norm + x2 upsampling of the coarser level + add: one launch
+                out = ops.gn_cl(lat.conv(pyramid[i]).contiguous(), lat.norm.weight, lat.norm.bias, lat.norm.eps,
+                                res=out.contiguous(), res_up2=True)
+            else:
+                out = upsample2_linear(out) + lat(pyramid[i])
         return self.output(out)[:, :, -1]
 
 

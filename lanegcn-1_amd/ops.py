@@ -503,19 +503,22 @@ def gn_fwd(x, gn=None, res=None, relu=False, eps=EPS):
     return out
 
 
-def gn_cl(x, gamma, beta, eps=EPS, res=None, relu=False):
-    """out = [ReLU](GroupNorm(1 group over (C, L))(x) [+ res]) for x [n, C, L]: ActorNet's conv norms in one launch."""
+def gn_cl(x, gamma, beta, eps=EPS, res=None, relu=False, res_up2=False):
+    """out = [ReLU](GroupNorm(1 group over (C, L))(x) [+ res]) for x [n, C, L]: ActorNet's conv norms in one launch.
+    res_up2: res is [n, C, L/2] and is upsampled x2 (linear, align_corners=False) on the fly (FPN top-down step)."""
     lib = L.load()
     x = _dev(x, torch.float32, "x")
     if x.dim() != 3:
         raise L.LgcnError("gn_cl: x must be [n, C, L]")
     res = None if res is None else _dev(res, torch.float32, "res")
-    if res is not None and res.shape != x.shape:
-        raise L.LgcnError("gn_cl: res must have the shape of x")
+    if res is not None:
+        want = (x.shape[0], x.shape[1], x.shape[2] // 2) if res_up2 else tuple(x.shape)
+        if tuple(res.shape) != want or (res_up2 and x.shape[2] % 2):
+            raise L.LgcnError("gn_cl: res has shape %s, expected %s" % (tuple(res.shape), want))
     out = torch.empty_like(x)
     gamma, beta = _dev(gamma.detach(), torch.float32, "gamma"), _dev(beta.detach(), torch.float32, "beta")
     L.check(lib.lgcn_gn_cl(_ptr(x), x.shape[0], x.shape[1], x.shape[2], _ptr(gamma), _ptr(beta), float(eps), _ptr(res),
-                           int(bool(relu)), _ptr(out), _stream()), "lgcn_gn_cl")
+                           int(bool(res_up2 and res is not None)), int(bool(relu)), _ptr(out), _stream()), "lgcn_gn_cl")
     return out
 
 

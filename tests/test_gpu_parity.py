@@ -546,3 +546,20 @@ def test_gn_cl_vs_torch_group_norm(hip, shape):
             want = want.relu() if relu else want
             got = ops.gn_cl(x.cuda(), gn.weight.cuda(), gn.bias.cuda(), gn.eps, res=res.cuda() if use_res else None, relu=relu)
             assert float((got.cpu().double() - want).abs().max()) <= 2e-5, (use_res, relu)
+
+
+def test_gn_cl_with_upsampled_residual(hip):
+    """res_up2: the FPN top-down step "interpolate(coarse, x2, linear) + lateral norm" in one launch vs torch."""
+    M, ops = hip
+    torch.manual_seed(5)
+    for n, C_, L_ in ((1600, 128, 10), (9, 128, 20), (4, 16, 2)):
+        x, coarse = torch.randn(n, C_, L_), torch.randn(n, C_, L_ // 2)
+        gn = torch.nn.GroupNorm(1, C_)
+        with torch.no_grad():
+            gn.weight.uniform_(0.5, 1.5)
+            gn.bias.uniform_(-0.5, 0.5)
+        up = torch.nn.functional.interpolate(coarse.double(), scale_factor=2, mode="linear", align_corners=False)
+        want = up + torch.nn.functional.group_norm(x.double(), 1, gn.weight.double(), gn.bias.double(), gn.eps)
+        got = ops.gn_cl(x.cuda(), gn.weight.cuda(), gn.bias.cuda(), gn.eps, res=coarse.cuda(), res_up2=True)
+        assert float((got.cpu().double() - want).abs().max()) <= 2e-5
+        assert float((M.upsample2_linear(coarse).double() - up).abs().max()) <= 1e-6      # the op-level fallback agrees too
