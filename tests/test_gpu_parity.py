@@ -563,3 +563,37 @@ def test_gn_cl_with_upsampled_residual(hip):
         got = ops.gn_cl(x.cuda(), gn.weight.cuda(), gn.bias.cuda(), gn.eps, res=coarse.cuda(), res_up2=True)
         assert float((got.cpu().double() - want).abs().max()) <= 2e-5
         assert float((M.upsample2_linear(coarse).double() - up).abs().max()) <= 1e-6      # the op-level fallback agrees too
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_ragged_batches_engine_vs_oracle(hip, ref_state_names, seed):
+    """Fuzz: 5-8 scenes of random size (road layouts, 1..37 actors), one scene shifted 5 km away from its actors
+    (no A2M / M2A pairs there: the legacy offset quirk in the middle of a batch), int16 indices; the flat engine
+    (batched pair search, CSR plan, fused kernels) against the oracle, every stage and the pair counts."""
+    M, ops = hip
+    from lanegcn_amd import data as gen
+    from lanegcn_amd.engine import HotPathEngine, collate_flat
+    rng = np.random.default_rng(100 + seed)
+    sd = O.seeded_state(ref_state_names, 20 + seed)
+    mods = make_modules(M, sd)
+    scenes_np = []
+    for j in range(int(rng.integers(5, 9))):
+        roads = [int(r) for r in rng.integers(4, 7, int(rng.integers(1, 4)))]
+        sc = gen.synth_scene(rng, roads, int(rng.integers(1, 38)), idx_dtype=np.int16)
+        if j == 2:
+            sc["ctrs"] = sc["ctrs"] + np.float32(5000.0)          # actors far from their map
+        scenes_np.append(sc)
+    scenes = [to_torch_scene(s) for s in scenes_np]
+    A_ = sum(len(s["ctrs"]) for s in scenes)
+    actors = torch.from_numpy(rng.normal(0, 1, (A_, 128)).astype(np.float32)).relu()
+    from lanegcn_amd.utils import to_long
+    want = O.hot_path(O.graph_gather([to_long(dict(s["graph"])) for s in scenes]), actors, [s["ctrs"] for s in scenes], sd)
+    eng = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"])
+    got = eng.forward(collate_flat(scenes_np), actors.cuda(), stages=True)
+    for k in ("map_net", "a2m", "m2m", "m2a", "a2a"):
+        err = float((got[k].cpu() - want[k]).abs().max())
+        assert err <= FTOL, (k, err)
+    node_ctrs, actor_ctrs = [s["graph"]["ctrs"] for s in scenes], [s["ctrs"] for s in scenes]
+    for n_dev, (a, c, th) in zip(got["n_pairs"], ((node_ctrs, actor_ctrs, 7.0), (actor_ctrs, node_ctrs, 6.0),
+                                                   (actor_ctrs, actor_ctrs, 100.0))):
+        assert int(n_dev.item()) == len(O.pair_search(a, c, th)[0])
