@@ -316,9 +316,11 @@ int lgcn_gn_fwd(const float *x, const float *gamma, const float *beta, const flo
  * res_up2 != 0: res is [n_items, C, L/2] (L even) and is upsampled x2 on the fly (linear, align_corners = False:
  * res'[2i] = 0.25 r[i-1] + 0.75 r[i], res'[2i+1] = 0.75 r[i] + 0.25 r[i+1], edges clamped) -- the top-down step of
  * the FPN, "interpolate(out, scale_factor=2, mode='linear') + lateral(x)", reference lanegcn.py:256-260.
+ * channels_last != 0: x, res and out are stored [n_items, L, C] (element = l * C + c), the layout in which MIOpen's
+ * convolutions run without transposes (torch.channels_last on [n, C, 1, L]).
  */
 int lgcn_gn_cl(const float *x, int64_t n_items, int C, int L, const float *gamma, const float *beta,
-               float eps, const float *res, int res_up2, int relu, float *out, void *stream);
+               float eps, const float *res, int res_up2, int relu, int channels_last, float *out, void *stream);
 
 /*
  * out[n] = sum_{j in [rowptr[n], rowptr[n+1])} src[col ? col[j] : j]   for n < n_rows (rows of 128 floats,

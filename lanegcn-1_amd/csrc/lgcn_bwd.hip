@@ -149,7 +149,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 __global__ __launch_bounds__(256) void k_gn_cl(const float *__restrict__ x, int64_t n_items, int C, int L,
                                                const float *__restrict__ gamma, const float *__restrict__ beta, float eps,
-                                               const float *__restrict__ res, int res_up2, int relu,
+                                               const float *__restrict__ res, int res_up2, int relu, int cl,
                                                float *__restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -166,14 +166,14 @@ __global__ __launch_bounds__(256) void k_gn_cl(const float *__restrict__ x, int6
     const float *ri = res ? res + item * (res_up2 ? C * Lh : n) : nullptr;
     float *oi = out + item * n;
     for (int i = lane; i < n; i += 64) {
-        const int c = i / L;
+        const int c = cl ? i % C : i / L;
         float v = (xi[i] - mean) * rstd * gamma[c] + beta[c];
         if (ri && res_up2) {
-            const int t = i - c * L, h = t >> 1;
-            const float *rc = ri + c * Lh;
-            const float mid = rc[h];
-            const float up = (t & 1) ? 0.75f * mid + 0.25f * rc[h + 1 < Lh ? h + 1 : Lh - 1]
-                                     : 0.25f * rc[h > 0 ? h - 1 : 0] + 0.75f * mid;
+            const int t = cl ? i / C : i - c * L, h = t >> 1;
+            const int hn = (t & 1) ? (h + 1 < Lh ? h + 1 : Lh - 1) : (h > 0 ? h - 1 : 0);     // the neighbour that contributes 1/4
+            const float mid = cl ? ri[h * C + c] : ri[c * Lh + h];
+            const float nb = cl ? ri[hn * C + c] : ri[c * Lh + hn];
+            const float up = (t & 1) ? 0.75f * mid + 0.25f * nb : 0.25f * nb + 0.75f * mid;
             v = up + v;
         } else if (ri) v += ri[i];
         if (relu) v = fmaxf(v, 0.f);
@@ -253,14 +253,14 @@ int lgcn_gn_fwd(const float *x, const float *gamma, const float *beta, const flo
 }
 
 int lgcn_gn_cl(const float *x, int64_t n_items, int C, int L, const float *gamma, const float *beta, float eps,
-               const float *res, int res_up2, int relu, float *out, void *stream) {
+               const float *res, int res_up2, int relu, int channels_last, float *out, void *stream) {
     if (n_items < 0 || C < 1 || L < 1 || (int64_t)C * L > 16384) return LGCN_EINVAL;
     if (res_up2 && (res == nullptr || (L & 1))) return LGCN_EINVAL;
     if (n_items == 0) return LGCN_OK;
     if (n_items > 0x7fffffff) return LGCN_ESHAPE;
     LGCN_CHECK_PTR(x); LGCN_CHECK_PTR(gamma); LGCN_CHECK_PTR(beta); LGCN_CHECK_PTR(out);
     hipLaunchKernelGGL(k_gn_cl, dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n_items, C, L,
-                       gamma, beta, eps, res, res_up2, relu, out);
+                       gamma, beta, eps, res, res_up2, relu, channels_last, out);
     return launch_status();
 }
 

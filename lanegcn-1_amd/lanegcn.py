@@ -502,7 +502,48 @@ class ActorNet(nn.Module):
         self.lateral = nn.ModuleList([Conv1d(w, n, norm="GN", ng=1, act=False) for w in widths])
         self.output = Res1d(n, n, norm="GN", ng=1)
 
+    def _forward_channels_last(self, actors: Tensor) -> Tensor:
+        """Inference path: the same FPN on [A, C, 1, L] tensors in torch.channels_last (memory [A, L, C]).  MIOpen
+        runs these convolutions 2-3x faster than the NCL ones (no layout transposes around its NHWC kernels:
+        128->128 at L = 20 takes 35 us instead of 59), and every norm / residual / ReLU / upsampling step in
+        between is one lgcn_gn_cl launch."""
+        cl = torch.channels_last
+
+        def conv(m: nn.Conv1d, x: Tensor) -> Tensor:
+            w = ops._cached(m.weight, ("cl4",), lambda: m.weight.detach().unsqueeze(2).contiguous(memory_format=cl))
+            return F.conv2d(x, w, stride=(1, m.stride[0]), padding=(0, m.padding[0]))
+
+        def gn(x, norm, **kw):
+            return ops.gn_cl(x, norm.weight, norm.bias, norm.eps, **kw)
+
+        def res1d(b: Res1d, x: Tensor) -> Tensor:
+            out = gn(conv(b.conv1, x), b.bn1, relu=True)
+            skip = x if b.downsample is None else gn(conv(b.downsample[0], x), b.downsample[1])
+            return gn(conv(b.conv2, out), b.bn2, relu=b.act, res=skip)
+
+        out, pyramid = actors.unsqueeze(2).contiguous(memory_format=cl), []
+        for g in self.groups:
+            for b in g:
+                out = res1d(b, out)
+            pyramid.append(out)
+        lat = self.lateral[-1]
+        out = gn(conv(lat.conv, pyramid[-1]), lat.norm, relu=lat.act)
+        for i in range(len(pyramid) - 2, -1, -1):
+            lat = self.lateral[i]
+            out = gn(conv(lat.conv, pyramid[i]), lat.norm, res=out, res_up2=True)
+        return res1d(self.output, out)[:, :, 0, -1]
+
+    def _channels_last_ok(self, actors: Tensor) -> bool:
+        mods = [b for g in self.groups for b in g] + [self.output]
+        norms = [m for b in mods for m in (b.bn1, b.bn2)] + [l.norm for l in self.lateral]
+        return (actors.is_cuda and actors.dtype == torch.float32 and actors.dim() == 3 and actors.shape[0] > 0
+                and actors.shape[2] % 4 == 0 and not ops.wants_grad(actors, *ops.module_params(self))
+                and all(isinstance(n, nn.GroupNorm) and n.num_groups == 1 for n in norms)
+                and not any(l.act for l in self.lateral[:-1]))
+
     def forward(self, actors: Tensor) -> Tensor:
+        if self._channels_last_ok(actors):
+            return self._forward_channels_last(actors)
         pyramid, out = [], actors
         for g in self.groups:
             out = g(out)

@@ -505,21 +505,38 @@ def gn_fwd(x, gn=None, res=None, relu=False, eps=EPS):
 
 
 def gn_cl(x, gamma, beta, eps=EPS, res=None, relu=False, res_up2=False):
-    """out = [ReLU](GroupNorm(1 group over (C, L))(x) [+ res]) for x [n, C, L]: ActorNet's conv norms in one launch.
-    res_up2: res is [n, C, L/2] and is upsampled x2 (linear, align_corners=False) on the fly (FPN top-down step)."""
+    """out = [ReLU](GroupNorm(1 group over (C, L))(x) [+ res]) in one launch: ActorNet's conv norms.
+    x: [n, C, L] contiguous, or [n, C, 1, L] in torch.channels_last (memory [n, L, C]: the layout MIOpen's
+    convolutions take without transposes); out has x's shape and layout.  res_up2: res is at half length and is
+    upsampled x2 (linear, align_corners=False) on the fly (FPN top-down step)."""
     lib = L.load()
-    x = _dev(x, torch.float32, "x")
-    if x.dim() != 3:
-        raise L.LgcnError("gn_cl: x must be [n, C, L]")
-    res = None if res is None else _dev(res, torch.float32, "res")
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise L.LgcnError("gn_cl: x must be a float32 CUDA tensor")
+    cl = x.dim() == 4
+    if cl:
+        if x.shape[2] != 1 or not x.is_contiguous(memory_format=torch.channels_last):
+            raise L.LgcnError("gn_cl: 4-D input must be [n, C, 1, L] in channels_last")
+        n, C_, L_ = x.shape[0], x.shape[1], x.shape[3]
+    elif x.dim() == 3:
+        x = x.contiguous()
+        n, C_, L_ = x.shape
+    else:
+        raise L.LgcnError("gn_cl: x must be [n, C, L] or [n, C, 1, L]")
     if res is not None:
-        want = (x.shape[0], x.shape[1], x.shape[2] // 2) if res_up2 else tuple(x.shape)
-        if tuple(res.shape) != want or (res_up2 and x.shape[2] % 2):
-            raise L.LgcnError("gn_cl: res has shape %s, expected %s" % (tuple(res.shape), want))
+        want = list(x.shape)
+        if res_up2:
+            want[-1] //= 2
+        if list(res.shape) != want or (res_up2 and L_ % 2) or not res.is_cuda or res.dtype != torch.float32:
+            raise L.LgcnError("gn_cl: res has shape %s, expected %s" % (tuple(res.shape), tuple(want)))
+        if cl and not res.is_contiguous(memory_format=torch.channels_last):
+            raise L.LgcnError("gn_cl: res must be channels_last like x")
+        if not cl:
+            res = res.contiguous()
     out = torch.empty_like(x)
     gamma, beta = _dev(gamma.detach(), torch.float32, "gamma"), _dev(beta.detach(), torch.float32, "beta")
-    L.check(lib.lgcn_gn_cl(_ptr(x), x.shape[0], x.shape[1], x.shape[2], _ptr(gamma), _ptr(beta), float(eps), _ptr(res),
-                           int(bool(res_up2 and res is not None)), int(bool(relu)), _ptr(out), _stream()), "lgcn_gn_cl")
+    L.check(lib.lgcn_gn_cl(_ptr(x), n, C_, L_, _ptr(gamma), _ptr(beta), float(eps), _ptr(res),
+                           int(bool(res_up2 and res is not None)), int(bool(relu)), int(cl), _ptr(out), _stream()),
+            "lgcn_gn_cl")
     return out
 
 

@@ -597,3 +597,26 @@ def test_random_ragged_batches_engine_vs_oracle(hip, ref_state_names, seed):
     for n_dev, (a, c, th) in zip(got["n_pairs"], ((node_ctrs, actor_ctrs, 7.0), (actor_ctrs, node_ctrs, 6.0),
                                                    (actor_ctrs, actor_ctrs, 100.0))):
         assert int(n_dev.item()) == len(O.pair_search(a, c, th)[0])
+
+
+def test_actor_net_channels_last_path_equals_stock_path(hip):
+    """ActorNet inference path (channels_last convolutions + lgcn_gn_cl glue) vs the stock NCL module path
+    (taken when autograd records) vs a CPU fp32 run of the same module."""
+    M, ops = hip
+    torch.manual_seed(11)
+    net = M.ActorNet(M.config).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.uniform_(0.5, 1.5) if p.mean() > 0.5 else p.uniform_(-0.3, 0.3)
+    x = torch.randn(333, 3, 20)
+    with torch.no_grad():
+        want = net(x)                                   # CPU: stock path
+    net = net.cuda()
+    with torch.no_grad():
+        got = net(x.cuda())                             # HIP glue + channels_last convolutions
+        assert net._channels_last_ok(x.cuda())
+    stock = net(x.cuda().requires_grad_(True)).detach() # autograd records: stock NCL path on the GPU
+    assert got.shape == (333, 128)
+    assert float((got.cpu() - want).abs().max()) <= 2e-4
+    assert float((got - stock).abs().max()) <= 2e-4
