@@ -323,6 +323,17 @@ int lgcn_gn_cl(const float *x, int64_t n_items, int C, int L, const float *gamma
                float eps, const float *res, int res_up2, int relu, int channels_last, float *out, void *stream);
 
 /*
+ * Backward of lgcn_gn_cl (layout [n_items, C, L], channels_last = 0):  given dy and the forward's x (and its
+ * output `post` when a ReLU was applied: the mask is post > 0),
+ *   g   = dy masked                      (also the gradient into res; written when g != NULL)
+ *   dx  = rstd * (g gamma - mean_item(g gamma) - xhat * mean_item(g gamma xhat))
+ *   part[item][0][c] = sum_l g xhat,  part[item][1][c] = sum_l g     (dgamma / dbeta = column sums over items)
+ * part: [n_items, 2, C] floats.  No atomics: the caller sums `part` over items.
+ */
+int lgcn_gn_cl_bwd(const float *dy, const float *x, const float *post, const float *gamma, int64_t n_items,
+                   int C, int L, float eps, float *dx, float *g, float *part, void *stream);
+
+/*
  * out[n] = sum_{j in [rowptr[n], rowptr[n+1])} src[col ? col[j] : j]   for n < n_rows (rows of 128 floats,
  * fixed summation order).  col == NULL: contiguous segments (index_add_ by a sorted index, lanegcn.py:703);
  * with col: a plain CSR (transposes of gathers in the backward).

@@ -67,6 +67,7 @@ SIGNATURES = {
     "lgcn_gn_bwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _P, _P]),
     "lgcn_gn_fwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _I, _P, _P]),
     "lgcn_gn_cl": (C.c_int, [_P, _L, _I, _I, _P, _P, _F, _P, _I, _I, _I, _P, _P]),
+    "lgcn_gn_cl_bwd": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _F, _P, _P, _P, _P]),
     "lgcn_wgrad": (C.c_int, [C.POINTER(AggMlp), _P, _P, _P, _I, _P]),
     "lgcn_gather_rows": (C.c_int, [_P, _P, _P, _L, _P, _P]),
     "lgcn_gather_sum": (C.c_int, [_P, _P, _P, _L, _P, _P]),

@@ -203,6 +203,29 @@ class GNActFn(Function):
         return dx, d_gw, d_gb, (g if ctx.has_res else None), None, None
 
 
+class GNCLFn(Function):
+    """out = [ReLU](GroupNorm(1 group over (C, L))(x) [+ res]) on [n, C, L]: ActorNet's conv norms (one launch
+    forward, one backward, instead of ~30 ATen launches of the explicit mean / var formula)."""
+
+    @staticmethod
+    def forward(ctx, x, gn_w, gn_b, res, relu: bool, eps: float):
+        x = x.contiguous()
+        out = ops.gn_cl(x, gn_w, gn_b, eps, res=res, relu=relu)
+        ctx.relu, ctx.eps, ctx.has_res = relu, eps, res is not None
+        ctx.save_for_backward(x, out, gn_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, out, gw = ctx.saved_tensors
+        dx, g, d_gw, d_gb = ops.gn_cl_bwd(d_out, x, out if ctx.relu else None, gw, eps=ctx.eps, want_g=ctx.has_res)
+        return dx, d_gw, d_gb, (g if ctx.has_res else None), None, None
+
+
+def gn_cl_act(x, gn, relu=False, res=None):
+    return GNCLFn.apply(x, gn.weight, gn.bias, res, relu, gn.eps)
+
+
 class PairAddFn(Function):
     """out[p] = c[p] + U[hi[p]] + V[wi[p]] (the hoisted query / context terms of lanegcn.py:696-699)."""
 

@@ -181,6 +181,54 @@ __global__ __launch_bounds__(256) void k_gn_cl(const float *__restrict__ x, int6
     }
 }
 
+// Backward of k_gn_cl, one wave per item: statistics recomputed, two item-wide sums (DPP-free wave_sum), then dx
+// element-wise and the per-channel sums of this item with one lane per channel (fixed order: deterministic).
+__global__ __launch_bounds__(256) void k_gn_cl_bwd(const float *__restrict__ dy, const float *__restrict__ x,
+                                                   const float *__restrict__ post, const float *__restrict__ gamma,
+                                                   int64_t n_items, int C, int L, float eps, float *__restrict__ dx,
+                                                   float *__restrict__ g_out, float *__restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const int n = C * L;
+    const float *xi = x + item * n, *di = dy + item * n;
+    const float *pi = post ? post + item * n : nullptr;
+    float s = 0.f;
+    for (int i = lane; i < n; i += 64) s += xi[i];
+    const float mean = wave_sum(s) / (float)n;
+    float q = 0.f;
+    for (int i = lane; i < n; i += 64) { const float d = xi[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)n + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = lane; i < n; i += 64) {
+        const float gv = (pi == nullptr || pi[i] > 0.f) ? di[i] : 0.f;
+        const float gg = gv * gamma[i / L];
+        s1 += gg;
+        s2 += gg * ((xi[i] - mean) * rstd);
+    }
+    const float m1 = wave_sum(s1) / (float)n, m2 = wave_sum(s2) / (float)n;
+    float *dxi = dx + item * n;
+    float *gi = g_out ? g_out + item * n : nullptr;
+    for (int i = lane; i < n; i += 64) {
+        const float gv = (pi == nullptr || pi[i] > 0.f) ? di[i] : 0.f;
+        const float xh = (xi[i] - mean) * rstd;
+        dxi[i] = rstd * (gv * gamma[i / L] - m1 - xh * m2);
+        if (gi) gi[i] = gv;
+    }
+    float *pt = part + item * 2 * C;
+    for (int c = lane; c < C; c += 64) {
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < L; ++l) {
+            const int i = c * L + l;
+            const float gv = (pi == nullptr || pi[i] > 0.f) ? di[i] : 0.f;
+            a += gv * ((xi[i] - mean) * rstd);
+            b += gv;
+        }
+        pt[c] = a;
+        pt[C + c] = b;
+    }
+}
+
 // one half-wave per output row, float4 per lane
 __global__ __launch_bounds__(256) void k_gather_sum(const float4 *__restrict__ src, const int32_t *__restrict__ rowptr,
                                                     const int32_t *__restrict__ col, int64_t n_rows,
@@ -261,6 +309,17 @@ int lgcn_gn_cl(const float *x, int64_t n_items, int C, int L, const float *gamma
     LGCN_CHECK_PTR(x); LGCN_CHECK_PTR(gamma); LGCN_CHECK_PTR(beta); LGCN_CHECK_PTR(out);
     hipLaunchKernelGGL(k_gn_cl, dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, n_items, C, L,
                        gamma, beta, eps, res, res_up2, relu, channels_last, out);
+    return launch_status();
+}
+
+int lgcn_gn_cl_bwd(const float *dy, const float *x, const float *post, const float *gamma, int64_t n_items, int C,
+                   int L, float eps, float *dx, float *g, float *part, void *stream) {
+    if (n_items < 0 || C < 1 || L < 1 || (int64_t)C * L > 16384) return LGCN_EINVAL;
+    if (n_items == 0) return LGCN_OK;
+    if (n_items > 0x7fffffff) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(dy); LGCN_CHECK_PTR(x); LGCN_CHECK_PTR(gamma); LGCN_CHECK_PTR(dx); LGCN_CHECK_PTR(part);
+    hipLaunchKernelGGL(k_gn_cl_bwd, dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, (hipStream_t)stream, dy, x, post,
+                       gamma, n_items, C, L, eps, dx, g, part);
     return launch_status();
 }
 

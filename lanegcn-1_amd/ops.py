@@ -540,6 +540,22 @@ def gn_cl(x, gamma, beta, eps=EPS, res=None, relu=False, res_up2=False):
     return out
 
 
+def gn_cl_bwd(dy, x, post, gamma, eps=EPS, want_g=False):
+    """Backward of gn_cl on [n, C, L]: (dx, g | None, dgamma, dbeta); post = forward output when it applied a ReLU."""
+    lib = L.load()
+    dy, x = _dev(dy, torch.float32, "dy").contiguous(), _dev(x, torch.float32, "x").contiguous()
+    n, C_, L_ = x.shape
+    post = None if post is None else _dev(post, torch.float32, "post").contiguous()
+    gamma = _dev(gamma.detach(), torch.float32, "gamma")
+    dx = torch.empty_like(x)
+    g = torch.empty_like(x) if want_g else None
+    part = torch.empty((n, 2, C_), dtype=torch.float32, device=x.device)
+    L.check(lib.lgcn_gn_cl_bwd(_ptr(dy), _ptr(x), _ptr(post), _ptr(gamma), n, C_, L_, float(eps), _ptr(dx), _ptr(g),
+                               _ptr(part), _stream()), "lgcn_gn_cl_bwd")
+    sums = part.sum(0)
+    return dx, g, sums[0], sums[1]
+
+
 def gn_bwd(dy, x, post, gamma, eps=EPS, want_g=False):
     """Backward of out = [ReLU](GN(x) [+res]): returns (dx, g, dgamma, dbeta); g = dy masked by post > 0
     (the gradient into `res`), None unless want_g.  gamma None: mask only."""

@@ -282,3 +282,39 @@ def test_refresh_packed_matches_single_packs(mode):
         assert ops.refresh_packed() == 0                        # nothing stale
     finally:
         ops.set_mma(prev)
+
+
+@pytest.mark.parametrize("shape", [(1600, 32, 20), (37, 64, 10), (130, 128, 5), (3, 7, 3)])
+def test_gn_cl_function_gradients_vs_fp64(shape):
+    """GNCLFn (ActorNet's norm + residual + ReLU, HIP forward and backward) against fp64 CPU autograd:
+    dx, dres, dgamma, dbeta."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import autograd as A
+    torch.manual_seed(shape[0])
+    n, C_, L_ = shape
+    gn = torch.nn.GroupNorm(1, C_)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+    x0, r0, w0 = torch.randn(n, C_, L_) * 2 + 0.3, torch.randn(n, C_, L_), torch.randn(n, C_, L_)
+    for use_res in (False, True):
+        for relu in (False, True):
+            xd, rd = x0.double().requires_grad_(True), r0.double().requires_grad_(True)
+            gd = torch.nn.GroupNorm(1, C_).double()
+            gd.load_state_dict({k: v.double() for k, v in gn.state_dict().items()})
+            ref = torch.nn.functional.group_norm(xd, 1, gd.weight, gd.bias, gn.eps)
+            ref = ref + rd if use_res else ref
+            ref = ref.relu() if relu else ref
+            (ref * w0.double()).sum().backward()
+            xg, rg = x0.cuda().requires_grad_(True), r0.cuda().requires_grad_(True)
+            gg = torch.nn.GroupNorm(1, C_).cuda()
+            gg.load_state_dict(gn.state_dict())
+            out = A.gn_cl_act(xg, gg, relu=relu, res=rg if use_res else None)
+            (out * w0.cuda()).sum().backward()
+            assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 2e-5
+            scale = lambda t: float(t.abs().max()) + 1e-9
+            assert float((xg.grad.cpu().double() - xd.grad).abs().max()) <= 2e-5 * scale(xd.grad) + 1e-6
+            if use_res:
+                assert float((rg.grad.cpu().double() - rd.grad).abs().max()) <= 1e-6
+            assert float((gg.weight.grad.cpu().double() - gd.weight.grad).abs().max()) <= 2e-5 * scale(gd.weight.grad)
+            assert float((gg.bias.grad.cpu().double() - gd.bias.grad).abs().max()) <= 2e-5 * scale(gd.bias.grad)
