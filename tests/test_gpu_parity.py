@@ -620,3 +620,30 @@ def test_actor_net_channels_last_path_equals_stock_path(hip):
     assert got.shape == (333, 128)
     assert float((got.cpu() - want).abs().max()) <= 2e-4
     assert float((got - stock).abs().max()) <= 2e-4
+
+
+@pytest.mark.parametrize("shape", [(1600, 128, 20), (77, 32, 20), (9, 64, 10), (4, 128, 5), (3, 6, 4)])
+def test_gn_cl_channels_last_layout(hip, shape):
+    """lgcn_gn_cl on [n, C, 1, L] channels_last tensors (memory [n, L, C]), incl. the upsampled residual, vs torch."""
+    M, ops = hip
+    torch.manual_seed(shape[1])
+    n, C_, L_ = shape
+    cl = torch.channels_last
+    x = torch.randn(n, C_, 1, L_) * 2 + 0.5
+    res = torch.randn(n, C_, 1, L_)
+    gn = torch.nn.GroupNorm(1, C_)
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.uniform_(-0.5, 0.5)
+    ref = torch.nn.functional.group_norm(x.double(), 1, gn.weight.double(), gn.bias.double(), gn.eps)
+    xc = x.cuda().contiguous(memory_format=cl)
+    got = ops.gn_cl(xc, gn.weight.cuda(), gn.bias.cuda(), gn.eps, res=res.cuda().contiguous(memory_format=cl), relu=True)
+    assert got.is_contiguous(memory_format=cl) and got.shape == x.shape
+    assert float((got.cpu().double() - (ref + res.double()).relu()).abs().max()) <= 2e-5
+    if L_ % 2 == 0:
+        coarse = torch.randn(n, C_, 1, L_ // 2)
+        up = torch.nn.functional.interpolate(coarse.double().squeeze(2), scale_factor=2, mode="linear",
+                                             align_corners=False).unsqueeze(2)
+        got = ops.gn_cl(xc, gn.weight.cuda(), gn.bias.cuda(), gn.eps, res=coarse.cuda().contiguous(memory_format=cl),
+                        res_up2=True)
+        assert float((got.cpu().double() - (up + ref)).abs().max()) <= 2e-5
