@@ -286,17 +286,24 @@ __device__ __forceinline__ void pairs_scan_bases_body(int32_t *rp, int n_agt, co
                                                       const int32_t *ctx_off, int n_scenes, int legacy, int64_t cap,
                                                       int32_t *hi_base, int32_t *wi_base, int32_t *n_pairs) {
     __shared__ int lds[1024 / 64 + 1];
-    const int per = (n_agt + 1024) / 1024;                  // ceil((T + 1) / 1024)
-    const int64_t b = (int64_t)threadIdx.x * per;
-    const int64_t e = b + per < (int64_t)n_agt + 1 ? b + per : (int64_t)n_agt + 1;
-    int sum = 0;
-    for (int64_t i = b; i < e; ++i) sum += i < n_agt ? rp[i] : 0;    // rp[T] holds no count
-    int tot;
-    int off = block_exclusive_scan<1024>(sum, &tot, lds);
-    for (int64_t i = b; i < e; ++i) {
-        const int v = i < n_agt ? rp[i] : 0;
-        rp[i] = off;
-        off += v;
+    // chunks of 4096 counts: every thread scans 4 consecutive ones (adjacent threads touch adjacent words)
+    int tot = 0;
+    for (int64_t c0 = 0; c0 <= n_agt; c0 += 4096) {
+        const int64_t b = c0 + 4 * (int64_t)threadIdx.x;
+        int v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[k] = b + k < n_agt ? rp[b + k] : 0;      // rp[T] holds no count
+            sum += v[k];
+        }
+        int chunk;
+        int off = block_exclusive_scan<1024>(sum, &chunk, lds) + tot;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (b + k <= n_agt) rp[b + k] = off;
+            off += v[k];
+        }
+        tot += chunk;
     }
     __syncthreads();    // the scanned table is read across threads below
     int carry_h = 0, carry_w = 0;
