@@ -14,6 +14,10 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef LGCN_RB_ONE
+#define LGCN_RB_ONE 3      // tile height (in 16-row blocks) built with the one-set weight ring and held to 128 VGPRs
+#endif
+
 namespace lgcn {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -171,6 +175,31 @@ __device__ __forceinline__ void ring_prime(BPair<F> &r, const uint4 *__restrict_
     load_b<F>(r.b[0], Bw, wave, lane, 0);
 }
 
+// Minimal variant: ONE fragment set (16 fewer VGPRs at NP = 2), the next K-step's fragments are requested as soon as
+// the current K-step's MFMAs are issued.  For 48-row tiles, where it is what lets two workgroups share a CU.
+template <int F>
+struct BOne { BFrag<F> b[1]; };
+
+template <int F>
+__device__ __forceinline__ void ring_prime(BOne<F> &r, const uint4 *__restrict__ Bw, int wave, int lane) {
+    load_b<F>(r.b[0], Bw, wave, lane, 0);
+}
+
+template <int RB, int F>
+__device__ __forceinline__ void gemm_pass(const uint16_t *__restrict__ A, const uint4 *__restrict__ Bw,
+                                          const uint4 *__restrict__ Bw_next, BOne<F> &r, int wave, int lane,
+                                          f32x4 (&acc)[RB][2]) {
+    const uint16_t *arow = A + (lane & 15) * kLDB + 8 * (lane >> 4);
+    kstep<RB, F>(arow, 0, r.b[0], acc);
+    load_b<F>(r.b[0], Bw, wave, lane, 1);
+    kstep<RB, F>(arow, 1, r.b[0], acc);
+    load_b<F>(r.b[0], Bw, wave, lane, 2);
+    kstep<RB, F>(arow, 2, r.b[0], acc);
+    load_b<F>(r.b[0], Bw, wave, lane, 3);
+    kstep<RB, F>(arow, 3, r.b[0], acc);
+    if (Bw_next != nullptr) load_b<F>(r.b[0], Bw_next, wave, lane, 0);
+}
+
 template <int RB, int F>
 __device__ __forceinline__ void gemm_pass(const uint16_t *__restrict__ A, const uint4 *__restrict__ Bw,
                                           const uint4 *__restrict__ Bw_next, BPair<F> &r, int wave, int lane,
@@ -207,6 +236,13 @@ __device__ __forceinline__ void gemm_pass(const uint16_t *__restrict__ A, const 
 template <int F>
 __device__ __forceinline__ void gemm2_prefetch(BPair<F> &r, const uint4 *__restrict__ Bw, int wave, int lane) {
     load_b<F>(r.b[1], Bw, wave, lane, 1);
+}
+template <int F>
+__device__ __forceinline__ void gemm2_prefetch(BOne<F> &, const uint4 *__restrict__, int, int) {}
+template <int RB, int F>
+__device__ __forceinline__ void gemm2_pass(const uint16_t *__restrict__ A, const uint4 *__restrict__ Bw, BOne<F> &r,
+                                           int wave, int lane, f32x4 (&acc)[RB][2]) {
+    gemm_pass<RB, F>(A, Bw, nullptr, r, wave, lane, acc);
 }
 template <int F>
 __device__ __forceinline__ void gemm2_prefetch(BRing<F> &r, const uint4 *__restrict__ Bw, int wave, int lane) {
@@ -330,18 +366,20 @@ struct TileIdx {
 // count: acc[RB][2]) and, where they fit, the second-edge rows in the spare weight-fragment set; both are
 // dead values on a gather wave.  This is what keeps 32-row tiles at 128 VGPRs (two workgroups per CU).
 template <int F, class Ring, int IT>
-struct XRows {   // second-edge rows: ring.b[1] when it has IT 16-B slots, a local array otherwise
-    static constexpr bool kAlias = IT <= 2 * Fmt<F>::NP;
+struct XRows {   // second-edge rows: the first slots live in the ring's LAST fragment set, the rest in a local array
+    static constexpr int kSets = sizeof(Ring) / sizeof(BFrag<F>);
+    static constexpr int kSlots = 2 * Fmt<F>::NP;                 // 16-B slots of one fragment set
+    static constexpr int kOwn = IT > kSlots ? IT - kSlots : 0;
     Ring &ring;
-    f32x4 own[kAlias ? 1 : IT];
+    f32x4 own[kOwn > 0 ? kOwn : 1];
     __device__ explicit XRows(Ring &r) : ring(r) {}
     __device__ __forceinline__ void set(int i, f32x4 v) {
-        if constexpr (kAlias) ring.b[1].v[i >> 1][i & 1] = __builtin_bit_cast(uint4, v);
-        else own[i] = v;
+        if (i < kSlots) ring.b[kSets - 1].v[i >> 1][i & 1] = __builtin_bit_cast(uint4, v);
+        else own[i - kSlots] = v;
     }
     __device__ __forceinline__ f32x4 get(int i) const {
-        if constexpr (kAlias) return __builtin_bit_cast(f32x4, ring.b[1].v[i >> 1][i & 1]);
-        else return own[i];
+        if (i < kSlots) return __builtin_bit_cast(f32x4, ring.b[kSets - 1].v[i >> 1][i & 1]);
+        return own[i - kSlots];
     }
 };
 
@@ -482,7 +520,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     const int flags = p.flags;
     const bool two = (flags & LGCN_F_GEMM2) != 0;
     const int gt = tid - 256;
-    typename std::conditional<DEEP, BRing<F>, BPair<F>>::type bfrag;
+    typename std::conditional<DEEP, BRing<F>, typename std::conditional<RB == LGCN_RB_ONE && F != 0, BOne<F>, BPair<F>>::type>::type bfrag;
     f32x4 acc[RB][2];       // MFMA waves: accumulators; gather waves: the row sums of the relation in flight
     int cadj[RB];
 #pragma unroll
@@ -706,10 +744,11 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
 // Tiles of <= 32 rows must keep two 8-wave workgroups per CU (4 waves per SIMD = 128 VGPRs): that co-residency
 // is what hides the weight-fragment latency; the register allocator is held to it (also where that costs a few
 // spilled registers: three-plane bf16x3 at RB = 2 runs 52 us held to 128 VGPRs, 74 us left free).
-#define LGCN_WAVES_PER_SIMD(RB_, DEEP_) __attribute__((amdgpu_waves_per_eu((RB_) <= 2 && !(DEEP_) ? 4 : 2)))
+#define LGCN_WAVES_PER_SIMD(RB_, DEEP_, F_) \
+    __attribute__((amdgpu_waves_per_eu(((RB_) <= 2 || ((RB_) == LGCN_RB_ONE && (F_) != 0)) && !(DEEP_) ? 4 : 2)))
 
 template <int RB, int F, int KIND, bool DEEP>
-__global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, DEEP) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
+__global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, DEEP, F) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4 + 4 * kC * 4];
     agg_body<RB, F, KIND, DEEP>(p, n_tiles, blockIdx.x, smem);
 }
@@ -717,7 +756,7 @@ __global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, DEEP) void k_agg_mlp_b
 // Two independent row blocks in one launch (Att's U and V: same shape of work, different inputs): blocks
 // [0, tiles_a) run problem a, the rest problem b.  One kernel boundary and one launch latency instead of two.
 template <int RB, int F>
-__global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, false) void k_agg_mlp_bf2(const lgcn_agg_mlp_t pa, const lgcn_agg_mlp_t pb, int tiles_a,
+__global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, false, F) void k_agg_mlp_bf2(const lgcn_agg_mlp_t pa, const lgcn_agg_mlp_t pb, int tiles_a,
                                                      int tiles_b) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4 + 4 * kC * 4];
     if ((int)blockIdx.x < tiles_a) agg_body<RB, F, 0, false>(pa, tiles_a, blockIdx.x, smem);
@@ -886,18 +925,24 @@ static int cu_count() {
     return n;
 }
 
-// 16-row blocks per tile.  Tiles of <= 32 rows (<= 128 VGPRs, <= 63 KB LDS) run two workgroups per CU,
-// taller ones one; pick the height with the fewest rounds x height, the taller on ties (weight reuse:
-// every tile streams the full weight set through L2 once).  Measured on S2 (10,368 rows): 32-row tiles
-// beat 48-row ones by 9 % alone and by 25 % with four forwards in flight.
-static int pick_rb(int64_t n_rows, int /*unused*/) {
+// 16-row blocks per tile.  Tiles of <= 32 rows (<= 128 VGPRs, <= 63 KB LDS) and, in the two-plane / one-plane modes,
+// 48-row tiles built with the one-set weight ring run two workgroups per CU, taller ones one; the generic rule picks
+// the height with the fewest rounds x height, the taller on ties (weight reuse: every tile streams the full weight
+// set through its CU's L1 once per relation).
+static int pick_rb(int64_t n_rows, int fmt, bool lane_conv = false) {
     const int64_t n_sub = (n_rows + 15) / 16;
+    auto slots = [&](int rb) { return (int64_t)cu_count() * (rb <= 2 || (rb == LGCN_RB_ONE && fmt != 0) ? 2 : 1); };
+    auto tiles = [&](int rb) { return (n_sub + rb - 1) / rb; };
+    // LaneConv with several forwards in flight: once 32-row tiles would put two workgroups on some CUs (more tiles
+    // than CUs), 48-row tiles are the better unit -- they still run two per CU (one-set weight ring, 126 VGPRs,
+    // 70 KB LDS), a whole launch fits the chip TWICE (216 tiles at S2: two streams' layers side by side instead of
+    // one and a third), and a row costs 1.8 KB instead of 2.5 KB through the CU's L1 per relation.  Measured at S2:
+    // 116 k vs 108 k scenes/s with four forwards in flight, 53.1 k vs 54.1 k with one.
+    if (lane_conv && LGCN_RB_ONE == 3 && fmt != 0 && tiles(2) > cu_count() && tiles(3) <= slots(3)) return 3;
     int best = 1;
     int64_t best_cost = -1;
     for (int rb = 1; rb <= 4; ++rb) {
-        const int64_t slots = (int64_t)cu_count() * (rb <= 2 ? 2 : 1);
-        const int64_t tiles = (n_sub + rb - 1) / rb;
-        const int64_t cost = ((tiles + slots - 1) / slots) * rb;
+        const int64_t cost = ((tiles(rb) + slots(rb) - 1) / slots(rb)) * rb;
         if (best_cost < 0 || cost <= best_cost) { best_cost = cost; best = rb; }
     }
     return best;
@@ -934,7 +979,7 @@ int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st) {
     int rb = p.tile_rb;
     if (rb < 0 || rb > 4) return LGCN_EINVAL;
     if (rb == 0 && lane_conv && force_rb_lc >= 1 && force_rb_lc <= 4) rb = force_rb_lc;
-    if (rb == 0) rb = force_rb >= 1 && force_rb <= 4 ? force_rb : pick_rb(p.n_rows, 1);
+    if (rb == 0) rb = force_rb >= 1 && force_rb <= 4 ? force_rb : pick_rb(p.n_rows, fmt_of(p.mma), lane_conv);
     const bool deep = ring >= 3;   // measured: no gain for the small row blocks either (U/V, Att tails)
     switch (fmt_of(p.mma)) {
         case 0: if (deep) launch_agg<0, true>(p, rb, lane_conv, st); else launch_agg<0, false>(p, rb, lane_conv, st); break;
@@ -946,7 +991,7 @@ int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st) {
 
 int agg_mlp_pair_bf(const lgcn_agg_mlp_t &a, const lgcn_agg_mlp_t &b, hipStream_t st) {
     // one tile height for both problems: the one picked for the larger of the two
-    const int rb = pick_rb(a.n_rows > b.n_rows ? a.n_rows : b.n_rows, 1);
+    const int rb = pick_rb(a.n_rows > b.n_rows ? a.n_rows : b.n_rows, fmt_of(a.mma));
     const int rows = 16 * rb;
     const int ta = (int)((a.n_rows + rows - 1) / rows), tb = (int)((b.n_rows + rows - 1) / rows);
 #define LGCN_AGG2(RB_, F_) hipLaunchKernelGGL((k_agg_mlp_bf2<RB_, F_>), dim3(ta + tb), dim3(512), 0, st, a, b, ta, tb)
@@ -962,7 +1007,7 @@ int agg_mlp_pair_bf(const lgcn_agg_mlp_t &a, const lgcn_agg_mlp_t &b, hipStream_
 }
 
 int mapnet_input_bf(const InputParams &p, int mma, hipStream_t st) {
-    const int rb = pick_rb(p.n_rows, 2);
+    const int rb = pick_rb(p.n_rows, fmt_of(mma));
     const int n_tiles = (int)((p.n_rows + 16 * rb - 1) / (16 * rb));
 #define LGCN_IN(RB_, F_) hipLaunchKernelGGL((k_mapnet_input_bf<RB_, F_>), dim3(n_tiles), dim3(256), 0, st, p, n_tiles)
 #define LGCN_IN_RB(F_) switch (rb) { case 1: LGCN_IN(1, F_); break; case 2: LGCN_IN(2, F_); break; case 3: LGCN_IN(3, F_); break; default: LGCN_IN(4, F_); }
