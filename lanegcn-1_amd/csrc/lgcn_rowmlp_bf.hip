@@ -647,9 +647,9 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     }
 
     // ---- epilogue.  The MFMA waves own the accumulators and the second GEMM; the row phases (GroupNorm,
-    // residual, ReLU, stores) run on waves 4..7, which have finished gathering: the residual rows are
-    // requested before the first row phase and arrive under it and the second GEMM, and the MFMA waves
-    // fetch the second weight's fragments while the rows are normalised.
+    // residual, ReLU, stores) of the first 32 rows run on waves 4..7, which have finished gathering: the residual
+    // rows are requested before the first row phase and arrive under it and the second GEMM, and the MFMA waves
+    // fetch the second weight's fragments before they normalise the rows above 32 (if the tile has any).
     constexpr int NCH = (ROWS + 31) / 32;       // 32-row chunks of the row phase (8 threads per row)
     const int rt = (tid - 256) & 255;           // row-phase thread id (masked: lets the compiler drop row < ROWS)
     if (wave < 4) {
@@ -675,40 +675,35 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     __syncthreads();
     LGCN_STAMP(41);
 
-    RowVals resv[NCH];      // residual rows: requested here, used after GroupNorm (one stage) or after the second GEMM
-    if (wave >= 4) {
+    // Row-phase ownership: rows 0..31 of the tile belong to waves 4..7 (thread rt -> row rt >> 3), rows 32.. (tiles
+    // of 48 / 64 rows) to the MFMA waves, which would otherwise idle through both row phases: each thread owns ONE
+    // row chunk and both halves run side by side.
+    const bool upper = wave < 4;                                   // this thread serves the rows above 32
+    const int my_rt = upper ? tid : rt;
+    const int my_row = (upper ? 32 : 0) + (my_rt >> 3);
+    const bool my_has_row = (upper ? NCH > 1 : true) && my_row < ROWS;      // 16-row tiles: half of waves 4..7 idle
+    const int64_t my_n = row0 + my_row;
+    const bool my_live = my_has_row && my_n < p.n_rows;
+    RowVals resv;     // residual row: requested here, used after GroupNorm (one stage) or after the second GEMM
+    if (two && upper) gemm2_prefetch<F>(bfrag, reinterpret_cast<const uint4 *>(p.wp2), wave, lane);
+    if (my_has_row) {
         {   // branch-free (row clamped, p.out read and ignored without a residual): behind a branch or a
             // predicate the compiler waits for these loads at the join, i.e. before the row phase starts
             const float *rbase = (flags & LGCN_F_RES) ? p.res : p.out;
+            const float *rp_ = rbase + (my_live ? my_n : 0) * kC + 4 * (my_rt & 7);
 #pragma unroll
-            for (int ch = 0; ch < NCH; ++ch) {
-                const int row = 32 * ch + (rt >> 3);
-                const int64_t n = row0 + row;
-                const float *rp_ = rbase + (row < ROWS && n < p.n_rows ? n : 0) * kC + 4 * (rt & 7);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) resv[ch].v[j] = *reinterpret_cast<const float4 *>(rp_ + 32 * j);
-            }
+            for (int j = 0; j < 4; ++j) resv.v[j] = *reinterpret_cast<const float4 *>(rp_ + 32 * j);
         }
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int row = 32 * ch + (rt >> 3);
-            if (row < ROWS) {
-                const int64_t n = row0 + row;
-                const bool live = n < p.n_rows;
-                RowVals r = row_load(T + 32 * ch * kLDA, rt);
+        RowVals r = row_load(T + (upper ? 32 : 0) * kLDA, my_rt);
 #ifndef LGCN_STAMPS
-                if (live && p.out_pre) row_store_global(p.out_pre + n * kC, rt, r);
+        if (my_live && p.out_pre) row_store_global(p.out_pre + my_n * kC, my_rt, r);
 #endif
-                if (flags & LGCN_F_GN1) row_gn(r, rt, gnp, gnp + kC, p.eps);
-                if (!two && live && (flags & LGCN_F_RES)) row_add(r, resv[ch]);
-                if (flags & LGCN_F_RELU1) row_relu(r);
-                if (two && live && p.out_mid) row_store_global(p.out_mid + n * kC, rt, r);
-                if (two) row_split_store<F>(Yp, TL::PLANE, row, rt, r);
-                else if (live) row_store_global(p.out + n * kC, rt, r);
-            }
-        }
-    } else if (two) {
-        gemm2_prefetch<F>(bfrag, reinterpret_cast<const uint4 *>(p.wp2), wave, lane);
+        if (flags & LGCN_F_GN1) row_gn(r, my_rt, gnp, gnp + kC, p.eps);
+        if (!two && my_live && (flags & LGCN_F_RES)) row_add(r, resv);
+        if (flags & LGCN_F_RELU1) row_relu(r);
+        if (two && my_live && p.out_mid) row_store_global(p.out_mid + my_n * kC, my_rt, r);
+        if (two) row_split_store<F>(Yp, TL::PLANE, my_row, my_rt, r);
+        else if (my_live) row_store_global(p.out + my_n * kC, my_rt, r);
     }
     if (!two) return;
     LGCN_STAMP(42);
@@ -722,21 +717,13 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     LGCN_STAMP(44);
     __syncthreads();
     LGCN_STAMP(45);
-    if (wave >= 4) {
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int row = 32 * ch + (rt >> 3);
-            if (row < ROWS) {
-                const int64_t n = row0 + row;
-                const bool live = n < p.n_rows;
-                RowVals r = row_load(T + 32 * ch * kLDA, rt);
-                if (live && p.out_pre2) row_store_global(p.out_pre2 + n * kC, rt, r);
-                if (flags & LGCN_F_GN2) row_gn(r, rt, gnp + 2 * kC, gnp + 3 * kC, p.eps);
-                if (live && (flags & LGCN_F_RES)) row_add(r, resv[ch]);
-                if (flags & LGCN_F_RELU2) row_relu(r);
-                if (live) row_store_global(p.out + n * kC, rt, r);
-            }
-        }
+    if (my_has_row) {
+        RowVals r = row_load(T + (upper ? 32 : 0) * kLDA, my_rt);
+        if (my_live && p.out_pre2) row_store_global(p.out_pre2 + my_n * kC, my_rt, r);
+        if (flags & LGCN_F_GN2) row_gn(r, my_rt, gnp + 2 * kC, gnp + 3 * kC, p.eps);
+        if (my_live && (flags & LGCN_F_RES)) row_add(r, resv);
+        if (flags & LGCN_F_RELU2) row_relu(r);
+        if (my_live) row_store_global(p.out + my_n * kC, my_rt, r);
     }
     LGCN_STAMP(46);
 }
