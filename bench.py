@@ -265,13 +265,18 @@ def main():
     else:
         # S independent batches, one captured forward each, replayed round-robin on S streams: step k runs
         # on stream k % S, so up to S forwards overlap on the GPU (every step is still a full batch-32 pass)
+        # the lane streams are created FIRST: torch hands out its pool streams in order and ROCm maps consecutive
+        # HIP streams to consecutive hardware queues (4 by default), so these S streams get S distinct queues;
+        # created between the captures (each capture takes a side stream from the same pool) lanes 0 / 2 and
+        # 1 / 3 shared a queue and only two forwards ever overlapped
+        lane_streams = [torch.cuda.Stream() for _ in range(args.streams)]
         lanes = []
         for j in range(args.streams):
             sc = scenes if j == 0 else gen.synth_batch(args.workload, seed=100 + rank + 1000 * j, n_scenes=args.scenes)
             fbj = fb if j == 0 else collate_flat(sc, dev)
             aj = actors if j == 0 else torch.randn(fbj.n_actors, C, device=dev).relu()
             gj, _ = eng.capture(fbj, aj, mapnet_only=args.mapnet_only)
-            lanes.append((torch.cuda.Stream(), gj))
+            lanes.append((lane_streams[j], gj))
         counter = [0]
 
         def step():
@@ -283,6 +288,13 @@ def main():
     barrier = D.barrier
 
     log("rank %d: forward %s" % (rank, "eager" if args.no_graph else "captured in a hipGraph"))
+    if os.environ.get("LGCN_BENCH_PREWARM") and not args.no_graph and args.streams > 1:
+        for n in range(1, len(lanes) + 1):
+            for r in range(60):
+                st_, g_ = lanes[r % n]
+                with torch.cuda.stream(st_):
+                    g_.replay()
+            torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()

@@ -233,6 +233,58 @@ typedef struct {
  */
 int lgcn_agg_mlp(const lgcn_agg_mlp_t *p_host, void *stream);
 
+/*
+ * LaneConv layer, gather-free and weight-stationary (reference lanegcn.py:331-362 == 448-479; the same arithmetic as
+ * lgcn_agg_mlp with the 15 relations, cut differently -- see csrc/lgcn_laneconv.hip):
+ *   T = sum_u (G_u X) W_u^T ;  Y = ReLU(GN1(T)) ;  out = ReLU(GN2(Y W2^T) + X)
+ * UNITS: u = 0 is ctr (the row itself), u = 1 + r is relation r of the lgcn_csr_build plan (pre0, suc0, ..., left,
+ * right).  Rows are cut into ROW BLOCKS of rows_per_block rows; a work item is (row block, run of consecutive
+ * units): its workgroup keeps every unit's weight slice in registers for the whole row block and reads the MFMA row
+ * operands straight from the item's DISTINCT source rows, which it loads once into LDS.  lgcn_lc_plan_build lists
+ * those rows once per batch (the lane graph is the same for the 8 LaneConv layers of a forward).
+ *
+ *   lgcn_lc_config      rows_per_block (variant 0: short row block, for batches that need the parallelism; variant 1:
+ *                       tall, half the weight traffic per row) and the LDS source-row capacity of a matrix mode
+ *                       (BF16X3 / F16X2 / BF16; F32 is not supported here: LGCN_ESHAPE, use lgcn_agg_mlp).
+ *   lgcn_lc_plan_build  rowptr / col: the lgcn_csr_build plan of n_rel relations (n_units = n_rel + 1 <= 15).
+ *                       gstart_host[0..n_groups]: unit groups, gstart[0] = 0 < ... < gstart[n_groups] = n_units;
+ *                       one workgroup per (row block, group).  n_groups = 1: a workgroup runs all units of its row
+ *                       block and finishes the layer itself (one launch, no partial sums); n_groups > 1: more
+ *                       parallelism for small batches, the groups' fp32 partial sums are added by a second launch.
+ *                       cap: source rows an item may hold, rows_per_block <= cap <= the mode's capacity; a group
+ *                       whose distinct sources exceed it is split into several items that the same workgroup runs
+ *                       one after the other (the results do not depend on cap or on the grouping beyond fp32
+ *                       summation order).  plan: lgcn_lc_plan_elems() int32 words, 16-byte aligned.
+ *   lgcn_laneconv_fwd   one layer: x [N,128] in, out [N,128]; wp[u] packed W_u (may be NULL for a relation without
+ *                       edges); part: workspace of lgcn_lc_part_elems() floats (unused when n_groups = 1).
+ *                       rows_per_block, cap, n_groups and gstart must be the ones the plan was built with.
+ *                       No atomics: bitwise repeatable.
+ */
+#define LGCN_LC_UNITS 15
+typedef struct {
+    int64_t n_rows;
+    const float *x;                   /* [N,128] layer input (also the residual) */
+    const float *wp[LGCN_LC_UNITS];   /* packed weights per unit                 */
+    const int32_t *col;               /* lgcn_csr_build col                      */
+    const int32_t *plan;              /* lgcn_lc_plan_build output               */
+    int32_t rows_per_block, cap, n_units, n_groups;
+    int32_t gstart[LGCN_LC_UNITS + 1];
+    const float *gn1_g, *gn1_b;
+    const float *wp2;
+    const float *gn2_g, *gn2_b;
+    float eps;
+    int32_t mma;
+    float *part;                      /* workspace                               */
+    float *out;                       /* [N,128]                                 */
+} lgcn_laneconv_t;
+int lgcn_lc_config(int mma, int variant, int32_t *rows_per_block, int32_t *cap);
+int64_t lgcn_lc_plan_elems(int64_t n_nodes, int rows_per_block, int cap);
+int64_t lgcn_lc_part_elems(int64_t n_nodes, int rows_per_block, int n_groups);
+int lgcn_lc_plan_build(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int n_rel,
+                       int rows_per_block, int cap, int n_groups, const int32_t *gstart_host,
+                       int32_t *plan, void *stream);
+int lgcn_laneconv_fwd(const lgcn_laneconv_t *p_host, void *stream);
+
 /* Two independent row blocks (e.g. Att's per-target U and per-context V, lanegcn.py:696-699) in ONE launch when both
  * are split-precision problems without CSR relations; otherwise the same as two lgcn_agg_mlp calls. */
 int lgcn_agg_mlp_pair(const lgcn_agg_mlp_t *a_host, const lgcn_agg_mlp_t *b_host, void *stream);

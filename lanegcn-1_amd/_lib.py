@@ -44,6 +44,20 @@ class AggMlp(C.Structure):
     ]
 
 
+LC_UNITS = 15
+
+
+class LaneConv(C.Structure):      # lgcn_laneconv_t
+    _fields_ = [
+        ("n_rows", C.c_int64), ("x", C.c_void_p), ("wp", C.c_void_p * LC_UNITS),
+        ("col", C.c_void_p), ("plan", C.c_void_p),
+        ("rows_per_block", C.c_int32), ("cap", C.c_int32), ("n_units", C.c_int32), ("n_groups", C.c_int32),
+        ("gstart", C.c_int32 * (LC_UNITS + 1)),
+        ("gn1_g", C.c_void_p), ("gn1_b", C.c_void_p), ("wp2", C.c_void_p), ("gn2_g", C.c_void_p), ("gn2_b", C.c_void_p),
+        ("eps", C.c_float), ("mma", C.c_int32), ("part", C.c_void_p), ("out", C.c_void_p),
+    ]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); every symbol include/lgcn.h declares
@@ -63,6 +77,11 @@ SIGNATURES = {
     "lgcn_pack_weight_t": (C.c_int, [_P, _I, _I, _P, _P]),
     "lgcn_pack_weight_batch": (C.c_int, [_P, _I, _I, _P]),
     "lgcn_agg_mlp": (C.c_int, [C.POINTER(AggMlp), _P]),
+    "lgcn_lc_config": (C.c_int, [_I, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "lgcn_lc_plan_elems": (C.c_int64, [_L, _I, _I]),
+    "lgcn_lc_part_elems": (C.c_int64, [_L, _I, _I]),
+    "lgcn_lc_plan_build": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, C.POINTER(C.c_int32), _P, _P]),
+    "lgcn_laneconv_fwd": (C.c_int, [C.POINTER(LaneConv), _P]),
     "lgcn_agg_mlp_pair": (C.c_int, [C.POINTER(AggMlp), C.POINTER(AggMlp), _P]),
     "lgcn_gn_bwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _P, _P]),
     "lgcn_gn_fwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _I, _P, _P]),

@@ -1,0 +1,741 @@
+// LaneConv layer (reference lanegcn.py:331-362 == 448-479) as a gather-free, weight-stationary pair of kernels.
+//
+//   T[n] = W_ctr X[n] + sum_r sum_{e: u_r[e] = n} W_r X[v_r[e]];  Y = ReLU(GN(T));  X' = ReLU(GN(W_ctr2 Y) + X)
+//
+// What bounds the one-kernel version (k_agg_mlp_bf, lgcn_rowmlp_bf.hip) is the byte rate at which ONE CU can pull
+// lines from L2 (~29 B/clk): every 48-row tile re-streams the whole 1 MB weight set and gathers every edge's source
+// row separately.  Here the work is cut the other way round:
+//
+//   * a ROW BLOCK is M = 192 rows (128 in the three-plane mode) and a work item is (row block, run of UNITS), a unit
+//     being one relation (ctr, pre0, suc0, ..., left, right).  A workgroup keeps one unit's weight slice in
+//     REGISTERS for all M rows (weight bytes per row through L1: 1/4 of the 48-row tile's) and its accumulators
+//     [M x 128] in registers too (8 waves = 4 channel quarters x 2 halves of K).
+//   * the DISTINCT source rows of the item are loaded ONCE into LDS as 16-bit operand planes (k_lc_plan lists them
+//     once per batch: the lane graph is the same for the 8 LaneConv layers of MapNet and M2M); the MFMA A operand
+//     of row n under unit u is read straight from the LDS row of its source through a per-row index -- there is no
+//     gather stage and no per-edge row load.  Rows with in-degree >= 2 under a relation get a VIRTUAL source row
+//     (the fp32 sum of their sources in index order, exactly what index_add_ forms), so a unit is always one pass.
+//   * the items of a row block write fp32 partial sums; k_lc_combine adds them in a fixed order and runs
+//     GN -> ReLU -> ctr2 -> GN -> + X -> ReLU.  No floating-point atomics: bitwise repeatable.
+#include "lgcn_common.hpp"
+#include "lgcn_tile.hpp"
+#include "lgcn_mma_bf.hpp"
+
+namespace lgcn {
+
+constexpr int kLcUnits = LGCN_LC_UNITS;     // ctr + up to 14 lane relations
+constexpr int kLcHdr = 8;                   // int32 words per item header
+
+// Two workgroup shapes per operand format (Fmt<F>); V = 0 "shared": a short row block and a source-row capacity that
+// keep the workgroup under half a CU (<= 78 KB of LDS, <= 128 VGPRs), so that two of them -- or one and another
+// stream's kernels -- share a CU and cover each other's loads and epilogues; V = 1 "tall": the whole CU, twice the
+// rows per weight byte, for batches with row blocks enough to fill the chip that way.
+//   RBN 16-row sub-blocks per row block; CAP source rows in LDS ((CAP + 1) rows x NP planes x 256 B: the extra row
+//   is all zero, rows without an edge point at it); HRB sub-blocks per epilogue phase.
+template <int F, int V> struct LcCfg;
+template <> struct LcCfg<0, 0> { static constexpr int RBN = 4, CAP = 96, HRB = 2; };      // bf16x3: 768 B per source row
+template <> struct LcCfg<0, 1> { static constexpr int RBN = 8, CAP = 200, HRB = 4; };
+template <> struct LcCfg<1, 0> { static constexpr int RBN = 6, CAP = 144, HRB = 2; };     // f16x2 : 512 B
+template <> struct LcCfg<1, 1> { static constexpr int RBN = 12, CAP = 304, HRB = 6; };
+template <> struct LcCfg<2, 0> { static constexpr int RBN = 6, CAP = 144, HRB = 2; };     // bf16  : 256 B
+template <> struct LcCfg<2, 1> { static constexpr int RBN = 12, CAP = 304, HRB = 6; };
+
+// Plan buffer (int32 words).  Item (b, u0) = row block b, units u0 .. u0 + n_span - 1; slot b * 15 + u0.
+//   hdr  [n_blocks*15][8] : n_live, n_src, n_span, 0, then 16 bytes: the live (non-empty) units of the item
+//   mask [n_blocks*15]    : per (block, unit): bit rb set when sub-block rb has an edge under the unit
+//   loc  [n_blocks*15][256] uint16 : per (block, unit): LDS source row of block row i at [(i & 15) * 16 + (i >> 4)],
+//                            0xFFFF = no edge
+//   src  [n_blocks*15][cap][2] : per item: (row, 0) = X[row];  (e0, deg >= 2) = sum_k X[col[e0 + k]]
+struct LcLayout {
+    int64_t n_blocks, hdr, mask, loc, src, total;
+    __host__ __device__ LcLayout(int64_t n_nodes, int M, int cap) {
+        n_blocks = (n_nodes + M - 1) / M;
+        const int64_t n = n_blocks * kLcUnits;
+        hdr = 0;
+        mask = hdr + n * kLcHdr;
+        loc = mask + ((n + 3) & ~(int64_t)3);
+        src = loc + n * 128;
+        total = src + n * cap * 2;
+    }
+};
+
+struct LcPlanParams {
+    const int32_t *rowptr, *col;
+    int64_t n_nodes;
+    int n_rel, M, cap, n_groups;
+    int gstart[kLcUnits + 2];
+    int32_t *plan;
+};
+
+// ---------------------------------------------------------------- plan -----
+// One workgroup per (row block, unit group); thread i = row i of the block.  Units are taken in order; the
+// distinct sources of the current item live in an LDS hash table.  Ids are handed out per unit in row order
+// (the first row that names a new source owns it), so the plan is a pure function of the graph.
+// When a unit's new sources would not fit `cap`, the item is closed and a new one starts at that unit.
+constexpr int kLcHash = 1024;
+
+__global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
+    __shared__ int hkey[kLcHash], hrow[kLcHash], hval[kLcHash];
+    __shared__ int s_w[4], s_cnt[4], s_ul[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / p.n_groups, g = blockIdx.x % p.n_groups;
+    const int u_begin = p.gstart[g], u_end = p.gstart[g + 1];
+    const LcLayout L(p.n_nodes, p.M, p.cap);
+    int32_t *hdr = p.plan + L.hdr, *maskp = p.plan + L.mask;
+    uint16_t *locp = reinterpret_cast<uint16_t *>(p.plan + L.loc);
+    int2 *srcp = reinterpret_cast<int2 *>(p.plan + L.src);
+    const int64_t n = (int64_t)b * p.M + tid;
+    const bool row_ok = tid < p.M && n < p.n_nodes;
+
+    auto clear = [&]() {
+        for (int i = tid; i < kLcHash; i += 256) { hkey[i] = -1; hrow[i] = 0x7fffffff; hval[i] = -1; }
+    };
+    auto finalize = [&](int u0, int n_live, int n_src, int span) {     // caller: all threads, followed by a barrier
+        if (tid < 4) {
+            int w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w |= (4 * tid + j < n_live ? s_ul[4 * tid + j] : 0) << (8 * j);
+            hdr[((int64_t)b * kLcUnits + u0) * kLcHdr + 4 + tid] = w;
+        }
+        if (tid == 0) {
+            int32_t *h = hdr + ((int64_t)b * kLcUnits + u0) * kLcHdr;
+            h[0] = n_live; h[1] = n_src; h[2] = span; h[3] = 0;
+        }
+    };
+
+    if (tid < u_end - u_begin) {     // headers of non-start units: no item
+        int32_t *h = hdr + ((int64_t)b * kLcUnits + u_begin + tid) * kLcHdr;
+#pragma unroll
+        for (int j = 0; j < kLcHdr; ++j) h[j] = 0;
+    }
+    clear();
+    __syncthreads();
+
+    int cur_u0 = u_begin, n_src = 0, n_live = 0;      // workgroup-uniform
+    for (int u = u_begin; u < u_end; ++u) {
+        int deg = 0, e0 = 0, key = -1;
+        if (row_ok) {
+            if (u == 0) { deg = 1; key = (int)n; }
+            else {
+                const int64_t k = ((n >> 4) * p.n_rel + (u - 1)) * 16 + (n & 15);
+                e0 = p.rowptr[k];
+                deg = p.rowptr[k + 1] - e0;
+                if (deg == 1) key = p.col[e0];
+            }
+        }
+        {
+            const unsigned long long bal = __ballot(deg > 0);
+            int wm = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if ((bal >> (16 * j)) & 0xffffull) wm |= 1 << (4 * wave + j);
+            if (lane == 0) s_w[wave] = wm;
+        }
+        __syncthreads();
+        const int mask = s_w[0] | s_w[1] | s_w[2] | s_w[3];
+        __syncthreads();                              // s_w is rewritten by the next unit
+        if (tid == 0) maskp[(int64_t)b * kLcUnits + u] = mask;
+        if (mask == 0) continue;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            int slot = 0;
+            if (deg == 1) {
+                unsigned h = ((unsigned)key * 2654435761u) >> 22;
+                for (;;) {
+                    const int k0 = atomicCAS(&hkey[h], -1, key);
+                    if (k0 == -1 || k0 == key) break;
+                    h = (h + 1) & (kLcHash - 1);
+                }
+                slot = (int)h;
+                atomicMin(&hrow[slot], tid);
+            }
+            __syncthreads();
+            bool winner = deg >= 2;
+            if (deg == 1) winner = hval[slot] < 0 && hrow[slot] == tid;
+            const unsigned long long bal = __ballot(winner);
+            const int wprefix = __popcll(bal & ((1ull << lane) - 1ull));
+            if (lane == 0) s_cnt[wave] = __popcll(bal);
+            __syncthreads();
+            int base = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { base += w < wave ? s_cnt[w] : 0; total += s_cnt[w]; }
+            if (n_src + total <= p.cap) {
+                int myid = -1;
+                if (winner) {
+                    myid = n_src + base + wprefix;
+                    srcp[((int64_t)b * kLcUnits + cur_u0) * p.cap + myid] = deg == 1 ? make_int2(key, 0) : make_int2(e0, deg);
+                    if (deg == 1) hval[slot] = myid;
+                }
+                if (tid == 0) s_ul[n_live] = u;
+                __syncthreads();
+                int loc = 0xffff;
+                if (deg == 1) loc = hval[slot];
+                else if (deg >= 2) loc = myid;
+                if (tid < p.M) locp[((int64_t)b * kLcUnits + u) * 256 + (tid & 15) * 16 + (tid >> 4)] = (uint16_t)loc;
+                n_src += total;
+                n_live += 1;
+                break;
+            }
+            // does not fit: close the item in front of this unit and start a new one here (always fits: total <= M <= cap)
+            finalize(cur_u0, n_live, n_src, u - cur_u0);
+            __syncthreads();
+            cur_u0 = u; n_src = 0; n_live = 0;
+            clear();
+            __syncthreads();
+        }
+    }
+    finalize(cur_u0, n_live, n_src, u_end - cur_u0);
+}
+
+// ---------------------------------------------------------------- tile -----
+struct LcTileParams {
+    const float *x;
+    int64_t n_rows;
+    const float *wp[kLcUnits];
+    const int32_t *col, *plan;
+    int n_blocks, n_groups, cap;
+    int gstart[kLcUnits + 2];
+    float *part;                      // n_groups > 1: partial sums [block][group][M][128]
+    // n_groups == 1: the layer is finished in this launch
+    const float *wp2, *gn1_g, *gn1_b, *gn2_g, *gn2_b;
+    float eps;
+    float *out;
+    unsigned long long *stamps;       // diagnostic build (-DLGCN_STAMPS) only: [workgroup][2][64] s_memtime stamps
+};
+
+// Source rows in LDS: row s at s * NP * 256 B, plane p at + p * 256 B, 16-byte slot q of the plane row at
+// ((q ^ (s & 15)) << 4): consecutive rows read by the 16 lanes of a ds_read_b128 group fall on 16 different slots.
+template <int F>
+__device__ __forceinline__ void lc_split_store(unsigned char *smem, int s, int l, f32x4 v) {
+    constexpr int NP = Fmt<F>::NP;
+    unsigned char *dst = smem + s * (NP * 256) + ((((l >> 1) ^ (s & 15)) << 4) | ((l & 1) << 3));
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const uint32_t a = Fmt<F>::pack(v[0], v[1]), b = Fmt<F>::pack(v[2], v[3]);
+        *reinterpret_cast<uint2 *>(dst + p * 256) = make_uint2(a, b);
+        if (p + 1 < NP) {
+            const f32x2 ra = Fmt<F>::unpack(a), rb = Fmt<F>::unpack(b);
+            v[0] -= ra.x; v[1] -= ra.y; v[2] -= rb.x; v[3] -= rb.y;
+        }
+    }
+}
+
+template <int F>
+struct LcW { uint4 v[Fmt<F>::NP][2][2]; };     // [plane][K-step of this wave's half][16-channel block]
+
+// LDS geometry of one (format, row-block height) instance.  Main loop: (CAP + 1) source rows.  Epilogue, per
+// phase of HR rows: the two K halves' fp32 tiles T0 | T1, then (finishing launches) the Y operand planes at LDS
+// rows YR0 .. YR0 + HR (YR0 a multiple of 16 so that the read swizzle of a Y row is its row number's).
+template <int F, int V>
+struct LcGeom {
+    static constexpr int RBN = LcCfg<F, V>::RBN, M = 16 * RBN, NP = Fmt<F>::NP, ROWB = NP * 256, CAP = LcCfg<F, V>::CAP;
+    static constexpr int HRB = LcCfg<F, V>::HRB, HR = 16 * HRB, PH = RBN / HRB;
+    static constexpr int T2_BYTES = 2 * HR * kLDA * 4;
+    static constexpr int YR0 = (((T2_BYTES + ROWB - 1) / ROWB + 15) / 16) * 16;
+    static constexpr int EP_BYTES = (YR0 + HR) * ROWB, SRC_BYTES = (CAP + 1) * ROWB;
+    static constexpr int SMEM = SRC_BYTES > EP_BYTES ? SRC_BYTES : EP_BYTES;
+    static_assert(RBN % HRB == 0 && SMEM <= (V == 0 ? 78 : 160) * 1024 - 256, "row block does not fit the LDS");
+};
+
+template <int F, int V, bool FIN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(V == 0 ? 4 : 2)))
+void k_lc_tile(const LcTileParams p) {
+    using G = LcGeom<F, V>;
+    constexpr int RBN = G::RBN, CAP = G::CAP, NP = G::NP, ROWB = G::ROWB, M = G::M, HRB = G::HRB, HR = G::HR, PH = G::PH;
+    constexpr int NIT = (CAP + 15) / 16;
+    constexpr bool DBUF = V == 1;                      // tall: a second weight-slice register set (256 VGPRs to spend)
+    constexpr int NLC = RBN > 8 ? 2 : 1;               // uint4 words of the per-row index
+    __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
+    __shared__ int s_ul[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cq = wave & 3, kh = wave >> 2;          // channel quarter, half of K
+    const int kq = lane >> 4;
+    const int item0 = xcd_chunk_remap(blockIdx.x, p.n_blocks * p.n_groups);
+    const int b = item0 / p.n_groups, g = item0 % p.n_groups;
+    const int uend = p.gstart[g + 1];
+    constexpr bool finish = FIN;                       // n_groups == 1: this launch also runs GN -> ctr2 -> GN -> + X -> ReLU
+    const LcLayout L(p.n_rows, M, p.cap);
+    const int32_t *hdr = p.plan + L.hdr;
+    const uint4 *locp = reinterpret_cast<const uint4 *>(p.plan + L.loc);
+    const int2 *srcp = reinterpret_cast<const int2 *>(p.plan + L.src);
+    const f32x4 *__restrict__ X = reinterpret_cast<const f32x4 *>(p.x);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#ifdef LGCN_STAMPS
+    unsigned long long *sbuf = p.stamps && (wave == 0 || wave == 7) ? p.stamps + ((int64_t)blockIdx.x * 2 + (wave == 7)) * 64 : nullptr;
+    int sidx = 0;
+#define LC_STAMP() do { if (lane == 0 && sbuf && sidx < 60) sbuf[sidx] = stamp(); ++sidx; } while (0)
+    if (lane == 0 && sbuf) sbuf[62] = __builtin_amdgcn_s_memrealtime();      // 100 MHz reference clock
+#else
+#define LC_STAMP() do { } while (0)
+#endif
+    LC_STAMP();   // 0: start
+
+    f32x4 acc[RBN][2];
+    acc_zero<RBN>(acc);
+    LcW<F> wc, wn;                                     // wn is used by the tall shape only
+    uint4 lc[NLC], ln[NLC];
+    auto load_w_ks = [&](const float *wp, LcW<F> &w, int ks) {     // K-step ks of this wave's weight slice
+        const uint4 *Wp = reinterpret_cast<const uint4 *>(wp);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+                w.v[pl][ks][cb] = Wp[((((pl * 4 + cq) * 4 + (2 * kh + ks)) * 2 + cb) << 6) + lane];
+    };
+    auto load_loc = [&](int uu, uint4 (&lo)[NLC]) {
+        const uint4 *lp = locp + (((int64_t)b * kLcUnits + uu) * 256 * 2) / 16 + (lane & 15) * 2;
+#pragma unroll
+        for (int j = 0; j < NLC; ++j) lo[j] = lp[j];
+    };
+    // one K = 128 pass over sub-blocks whose LDS rows are given per lane: the A fragments of K-step ks of sub-block
+    // rb + 1 are requested as soon as the MFMAs of K-step ks of sub-block rb have consumed their registers
+    auto rd = [&](uint32_t row, int ks, uint4 (&a)[NP]) {
+        const uint32_t slot = (uint32_t)(((2 * kh + ks) << 2) | kq) ^ (row & 15u);
+        const unsigned char *q = smem + row * ROWB + (slot << 4);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) a[pl] = *reinterpret_cast<const uint4 *>(q + pl * 256);
+    };
+    auto mm = [&](f32x4 (&c2)[2], int ks, const uint4 (&a)[NP]) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x4 c = c2[cb];
+#pragma unroll
+            for (int q = 0; q < Fmt<F>::NPROD; ++q)      // smallest terms first
+                c = Fmt<F>::mfma(a[Fmt<F>::PA[q]], wc.v[Fmt<F>::PB[q]][ks][cb], c);
+            c2[cb] = c;
+        }
+    };
+
+    for (int u0 = p.gstart[g]; u0 < uend;) {
+        const int64_t item = (int64_t)b * kLcUnits + u0;
+        const int4 h = *reinterpret_cast<const int4 *>(hdr + item * kLcHdr);
+        const int4 hu = *reinterpret_cast<const int4 *>(hdr + item * kLcHdr + 4);
+        const int n_live = __builtin_amdgcn_readfirstlane(h.x), n_src = __builtin_amdgcn_readfirstlane(h.y);
+        const int span = __builtin_amdgcn_readfirstlane(h.z) > 0 ? __builtin_amdgcn_readfirstlane(h.z) : 1;
+        if (n_live <= 0) { u0 += span; continue; }
+        const bool last_item = u0 + span >= uend;
+
+        // ---- the item's source rows -> LDS planes (one half-wave per row, the row loads of a batch in flight
+        // together); the first unit's weight slice + row index are requested before them and used after them
+        LC_STAMP();   // header in
+        const int uf = __builtin_amdgcn_readfirstlane(hu.x & 0xff);
+        if (DBUF) {       // tall shape: registers to spare, the slice arrives under the loader
+            load_w_ks(p.wp[uf], wc, 0);
+            load_w_ks(p.wp[uf], wc, 1);
+            load_loc(uf, lc);
+        }
+        if (tid < ROWB / 16) reinterpret_cast<uint4 *>(smem + CAP * ROWB)[tid] = make_uint4(0, 0, 0, 0);
+        {
+            // the opaque zero keeps the loader's per-row addressing (invariant across items) out of the loop
+            // pre-header, where the hoisted values would sit in registers / scratch for the whole kernel
+            int opq = 0;
+            asm volatile("" : "+v"(opq));
+            const int hw = (tid >> 5) + opq, l = (tid & 31) + opq;
+            const int2 *sl = srcp + item * p.cap;
+            int2 e[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {      // unconditional loads (index clamped): one round trip for all
+                const int s = it * 16 + hw;
+                e[it] = sl[s < p.cap ? s : p.cap - 1];
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it)
+                if (it * 16 + hw >= n_src) e[it] = make_int2(0, -1);   // y < 0: no row
+            constexpr int NH = DBUF ? (NIT + 1) / 2 : (NIT + 1) / 2 < 5 ? (NIT + 1) / 2 : 5;   // row loads in flight per lane (registers)
+#pragma unroll
+            for (int h0 = 0; h0 < NIT; h0 += NH) {
+                f32x4 v[NH];
+#pragma unroll
+                for (int j = 0; j < NH; ++j) {
+                    const int it = h0 + j < NIT ? h0 + j : NIT - 1;
+                    const unsigned r = e[it].y == 0 ? (unsigned)e[it].x : 0u;
+                    v[j] = X[((uint64_t)r << 5) + l];                // unconditional (row 0 when unused)
+                }
+#pragma unroll
+                for (int j = 0; j < NH; ++j) {
+                    if (h0 + j < NIT && e[h0 + j].y > 0) {           // virtual row: fp32 sum in index order
+                        f32x4 a = zero4;
+                        for (int k = 0; k < e[h0 + j].y; ++k)
+                            a = a + X[((uint64_t)(unsigned)p.col[e[h0 + j].x + k] << 5) + l];
+                        v[j] = a;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NH; ++j)
+                    if (h0 + j < NIT && e[h0 + j].y >= 0) lc_split_store<F>(smem, (h0 + j) * 16 + hw, l, v[j]);
+            }
+        }
+        if (tid < 16) {
+            const int w = (tid >> 2) == 0 ? hu.x : (tid >> 2) == 1 ? hu.y : (tid >> 2) == 2 ? hu.z : hu.w;
+            s_ul[tid] = (w >> (8 * (tid & 3))) & 0xff;
+        }
+        if (!DBUF) {      // shared shape: requested behind the row loads; arrives under the barrier / the other workgroup
+            load_w_ks(p.wp[uf], wc, 0);
+            load_w_ks(p.wp[uf], wc, 1);
+            load_loc(uf, lc);
+        }
+        LC_STAMP();   // own source rows stored
+        __syncthreads();
+        LC_STAMP();   // barrier passed
+
+        // ---- units.  Sub-blocks without an edge under a unit read the zero row (their index entries are 0xFFFF),
+        // so a pass is one straight line.  The weight slice + row index of the NEXT unit (or the second weight,
+        // behind the last unit of a finishing launch): tall shape -- fetched into a second register set while
+        // this unit's MFMAs run; shared shape -- each K-step's registers are refilled as soon as the last
+        // sub-block has used them (the co-resident workgroup covers what latency that leaves).
+        for (int k = 0; k < n_live; ++k) {
+            const bool more = k + 1 < n_live, tail2 = !more && last_item && finish;
+            const int un = more ? __builtin_amdgcn_readfirstlane(s_ul[k + 1]) : 0;
+            const float *wnext = more ? p.wp[un] : p.wp2;
+            if (DBUF) {
+                if (more || tail2) { load_w_ks(wnext, wn, 0); load_w_ks(wnext, wn, 1); }
+                if (more) load_loc(un, ln);
+            }
+            uint32_t lw[4 * NLC];
+#pragma unroll
+            for (int j = 0; j < NLC; ++j) { lw[4 * j] = lc[j].x; lw[4 * j + 1] = lc[j].y; lw[4 * j + 2] = lc[j].z; lw[4 * j + 3] = lc[j].w; }
+            auto row_of = [&](int rb) -> uint32_t {
+                const uint32_t w16 = (lw[rb >> 1] >> (16 * (rb & 1))) & 0xffffu;
+                return w16 == 0xffffu ? (uint32_t)CAP : w16;
+            };
+            uint4 a0[NP], a1[NP];
+            rd(row_of(0), 0, a0);
+            rd(row_of(0), 1, a1);
+#pragma unroll
+            for (int rb = 0; rb < RBN; ++rb) {
+                __builtin_amdgcn_sched_barrier(0);
+                mm(acc[rb], 0, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rb + 1 < RBN) rd(row_of(rb + 1), 0, a0);
+                else if (!DBUF && (more || tail2)) load_w_ks(wnext, wc, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(acc[rb], 1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rb + 1 < RBN) rd(row_of(rb + 1), 1, a1);
+                else if (!DBUF && (more || tail2)) load_w_ks(wnext, wc, 1);
+            }
+            if (DBUF) {
+                if (more || tail2) wc = wn;
+                if (more) {
+#pragma unroll
+                    for (int j = 0; j < NLC; ++j) lc[j] = ln[j];
+                }
+            } else if (more) {
+                load_loc(un, lc);
+            }
+            LC_STAMP();   // unit k done
+        }
+        LC_STAMP();       // loop done
+        __syncthreads();  // every wave is done with the source rows (next item's rows / the epilogue tiles go there)
+        u0 += span;
+    }
+
+    // ---- epilogue, HR rows at a time: each K half stores its accumulators into its own fp32 tile, the row threads
+    // add the two tiles on the way out (8 threads per row, 512-B coalesced rows).  A finishing launch goes on:
+    // GN -> ReLU -> operand planes -> ctr2 on the matrix cores (same K split) -> GN -> + X -> ReLU -> out.
+    float *T0 = reinterpret_cast<float *>(smem);
+    float *Tk = T0 + kh * (HR * kLDA);
+    constexpr int SW = (HR + 63) / 64;              // sweeps of 64 rows
+    auto tiles_from_acc = [&](int ph) {
+#pragma unroll
+        for (int rb = 0; rb < HRB; ++rb)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+                float *q = Tk + (16 * rb + 4 * (lane >> 4)) * kLDA + 32 * cq + 16 * cb + (lane & 15);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) q[i * kLDA] = acc[ph * HRB + rb][cb][i];
+            }
+    };
+    auto tile_row = [&](int sweep) {
+        RowVals r = row_load(T0 + sweep * 64 * kLDA, tid);
+        row_add(r, row_load(T0 + (HR + sweep * 64) * kLDA, tid));
+        return r;
+    };
+    LC_STAMP();           // epilogue starts
+#pragma unroll
+    for (int ph = 0; ph < PH; ++ph) {
+        RowVals resv[SW];
+        if (finish) {     // residual rows: requested here, used at the very end of the phase
+#pragma unroll
+            for (int sweep = 0; sweep < SW; ++sweep) {
+                const int64_t n = (int64_t)b * M + ph * HR + sweep * 64 + (tid >> 3);
+                const float *rp_ = p.x + (n < p.n_rows ? n : 0) * kC + 4 * (tid & 7);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) resv[sweep].v[j] = *reinterpret_cast<const float4 *>(rp_ + 32 * j);
+            }
+        }
+        tiles_from_acc(ph);
+        __syncthreads();
+        LC_STAMP();       // both K halves of this row half in LDS
+#pragma unroll
+        for (int sweep = 0; sweep < SW; ++sweep) {
+            const int hrow = sweep * 64 + (tid >> 3);
+            if (hrow < HR) {
+                RowVals r = tile_row(sweep);
+                const int row = ph * HR + hrow;
+                if (!finish) {
+                    if ((int64_t)b * M + row < p.n_rows)
+                        row_store_global(p.part + (((int64_t)b * p.n_groups + g) * M + row) * kC, tid, r);
+                } else {
+                    row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
+                    row_relu(r);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        lc_split_store<F>(smem, G::YR0 + hrow, (tid & 7) + 8 * j,
+                                          f32x4{r.v[j].x, r.v[j].y, r.v[j].z, r.v[j].w});
+                }
+            }
+        }
+        if (finish) {
+            __syncthreads();          // Y planes complete; every read of T0 | T1 is done
+#pragma unroll
+            for (int rb = 0; rb < HRB; ++rb) {
+                acc[ph * HRB + rb][0] = zero4;
+                acc[ph * HRB + rb][1] = zero4;
+            }
+            uint4 a0[NP], a1[NP];
+            const uint32_t yrow = (uint32_t)G::YR0 + (lane & 15);
+            rd(yrow, 0, a0);
+            rd(yrow, 1, a1);
+#pragma unroll
+            for (int rb = 0; rb < HRB; ++rb) {
+                __builtin_amdgcn_sched_barrier(0);
+                mm(acc[ph * HRB + rb], 0, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rb + 1 < HRB) rd(yrow + 16 * (rb + 1), 0, a0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(acc[ph * HRB + rb], 1, a1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (rb + 1 < HRB) rd(yrow + 16 * (rb + 1), 1, a1);
+            }
+            tiles_from_acc(ph);       // T0 | T1 and the Y planes are disjoint
+            __syncthreads();
+#pragma unroll
+            for (int sweep = 0; sweep < SW; ++sweep) {
+                const int hrow = sweep * 64 + (tid >> 3);
+                const int64_t n = (int64_t)b * M + ph * HR + hrow;
+                if (hrow < HR) {
+                    RowVals r = tile_row(sweep);
+                    row_gn(r, tid, p.gn2_g, p.gn2_b, p.eps);
+                    row_add(r, resv[sweep]);
+                    row_relu(r);
+                    if (n < p.n_rows) row_store_global(p.out + n * kC, tid, r);
+                }
+            }
+        }
+        if (ph + 1 < PH) __syncthreads();     // the next row half overwrites the tiles (and the Y planes)
+    }
+    LC_STAMP();           // rows stored
+#ifdef LGCN_STAMPS
+    if (lane == 0 && sbuf) { sbuf[63] = __builtin_amdgcn_s_memrealtime(); sbuf[61] = stamp(); }
+#endif
+}
+
+// ------------------------------------------------------------- combine -----
+struct LcCombParams {
+    const float *part;
+    int64_t n_rows;
+    int M, n_groups;
+    const float *res, *wp2, *gn1_g, *gn1_b, *gn2_g, *gn2_b;
+    float eps;
+    float *out;
+};
+
+// 32-row tiles, 4 waves: T = sum of the row block's partials (group order) -> GN -> ReLU -> planes -> ctr2 on the
+// matrix cores -> GN -> + X -> ReLU.
+template <int F>
+__global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_tiles) {
+    using TL = Tile<2, F>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TL::ABUF_BYTES + TL::T_BYTES];
+    uint16_t *A = reinterpret_cast<uint16_t *>(smem);
+    float *T = reinterpret_cast<float *>(smem + TL::ABUF_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tile = xcd_chunk_remap(blockIdx.x, n_tiles);
+    const int64_t row0 = (int64_t)tile * 32;
+    const int b = (int)(row0 / p.M), rib0 = (int)(row0 % p.M);
+    const uint4 *wp2 = reinterpret_cast<const uint4 *>(p.wp2);
+
+    BPair<F> bf;
+    ring_prime<F>(bf, wp2, wave, lane);
+    const int row = tid >> 3;
+    const int64_t n = row0 + row;
+    const bool live_row = n < p.n_rows;
+    RowVals resv;
+    {
+        const float *rp_ = p.res + (live_row ? n : 0) * kC + 4 * (tid & 7);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) resv.v[j] = *reinterpret_cast<const float4 *>(rp_ + 32 * j);
+    }
+    RowVals r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t prow = (int64_t)(live_row ? rib0 + row : rib0);
+    const int cnt = p.n_groups;
+    for (int j0 = 0; j0 < cnt; j0 += 4) {       // four partial rows in flight; added in group order
+        RowVals x[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = j0 + q < cnt ? j0 + q : cnt - 1;
+            const float *pp = p.part + (((int64_t)b * cnt + id) * p.M + prow) * kC + 4 * (tid & 7);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[q].v[j] = *reinterpret_cast<const float4 *>(pp + 32 * j);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (j0 + q < cnt) row_add(r, x[q]);
+    }
+    if (!live_row) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
+    row_relu(r);
+    row_split_store<F>(A, TL::PLANE, row, tid, r);
+    __syncthreads();
+    f32x4 acc[2][2];
+    acc_zero<2>(acc);
+    gemm_pass<2, F>(A, wp2, nullptr, bf, wave, lane, acc);
+    acc_store<2>(T, acc, lane, wave);
+    __syncthreads();
+    r = row_load(T, tid);
+    row_gn(r, tid, p.gn2_g, p.gn2_b, p.eps);
+    row_add(r, resv);
+    row_relu(r);
+    if (live_row) row_store_global(p.out + n * kC, tid, r);
+}
+
+static int fmt_of(int mma) { return mma == LGCN_MMA_BF16X3 ? 0 : mma == LGCN_MMA_F16X2 ? 1 : 2; }
+
+static bool lc_cfg(int mma, int variant, int *M, int *cap) {
+    if (variant < 0 || variant > 1) return false;
+#define LGCN_CFG(F_) do { if (variant) { *M = 16 * LcCfg<F_, 1>::RBN; *cap = LcCfg<F_, 1>::CAP; } else { *M = 16 * LcCfg<F_, 0>::RBN; *cap = LcCfg<F_, 0>::CAP; } } while (0)
+    switch (fmt_of(mma)) {
+        case 0: LGCN_CFG(0); break;
+        case 1: LGCN_CFG(1); break;
+        default: LGCN_CFG(2); break;
+    }
+#undef LGCN_CFG
+    return true;
+}
+
+}  // namespace lgcn
+
+using namespace lgcn;
+
+#ifdef LGCN_STAMPS
+static unsigned long long *g_lc_stamps = nullptr;     // diagnostic build only (tools/stamps_lc.py)
+extern "C" void lgcn_debug_lc_stamps(void *buf) { g_lc_stamps = reinterpret_cast<unsigned long long *>(buf); }
+#endif
+
+extern "C" {
+
+static bool lc_mma_ok(int mma) { return mma == LGCN_MMA_BF16X3 || mma == LGCN_MMA_F16X2 || mma == LGCN_MMA_BF16; }
+
+int lgcn_lc_config(int mma, int variant, int32_t *rows_per_block, int32_t *cap) {
+    if (!lc_mma_ok(mma)) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(rows_per_block); LGCN_CHECK_PTR(cap);
+    int M, c;
+    if (!lc_cfg(mma, variant, &M, &c)) return LGCN_EINVAL;
+    *rows_per_block = M;
+    *cap = c;
+    return LGCN_OK;
+}
+
+static bool lc_geom_ok(int64_t n_nodes, int M, int cap) {
+    return n_nodes >= 0 && n_nodes <= 0x7fffffff && (M == 64 || M == 96 || M == 128 || M == 192) && cap >= M &&
+           cap <= kLcHash / 2;
+}
+
+int64_t lgcn_lc_plan_elems(int64_t n_nodes, int rows_per_block, int cap) {
+    if (!lc_geom_ok(n_nodes, rows_per_block, cap)) return LGCN_EINVAL;
+    return LcLayout(n_nodes, rows_per_block, cap).total;
+}
+
+int64_t lgcn_lc_part_elems(int64_t n_nodes, int rows_per_block, int n_groups) {
+    if (!lc_geom_ok(n_nodes, rows_per_block, rows_per_block) || n_groups < 1 || n_groups > kLcUnits) return LGCN_EINVAL;
+    if (n_groups == 1) return 0;          // the layer is finished in one launch: no partial sums
+    return ((n_nodes + rows_per_block - 1) / rows_per_block) * n_groups * rows_per_block * kC;
+}
+
+static int lc_groups_ok(int n_units, int n_groups, const int32_t *gstart) {
+    if (n_units < 1 || n_units > kLcUnits || n_groups < 1 || n_groups > n_units || gstart == nullptr) return 0;
+    if (gstart[0] != 0 || gstart[n_groups] != n_units) return 0;
+    for (int g = 0; g < n_groups; ++g)
+        if (gstart[g + 1] <= gstart[g]) return 0;
+    return 1;
+}
+
+int lgcn_lc_plan_build(const int32_t *rowptr, const int32_t *col, int64_t n_nodes, int n_rel, int rows_per_block,
+                       int cap, int n_groups, const int32_t *gstart_host, int32_t *plan, void *stream) {
+    if (n_rel < 0 || n_rel > kLcUnits - 1 || !lc_geom_ok(n_nodes, rows_per_block, cap)) return LGCN_EINVAL;
+    if (!lc_groups_ok(n_rel + 1, n_groups, gstart_host)) return LGCN_EINVAL;
+    if (n_nodes == 0) return LGCN_OK;
+    LGCN_CHECK_PTR(plan); LGCN_CHECK_ALIGN16(plan);
+    if (n_rel > 0) { LGCN_CHECK_PTR(rowptr); LGCN_CHECK_PTR(col); }
+    LcPlanParams p;
+    p.rowptr = rowptr; p.col = col; p.n_nodes = n_nodes; p.n_rel = n_rel; p.M = rows_per_block; p.cap = cap;
+    p.n_groups = n_groups;
+    for (int g = 0; g <= n_groups; ++g) p.gstart[g] = gstart_host[g];
+    for (int g = n_groups + 1; g < kLcUnits + 2; ++g) p.gstart[g] = gstart_host[n_groups];
+    p.plan = plan;
+    const int64_t n_blocks = (n_nodes + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(k_lc_plan, dim3((unsigned)(n_blocks * n_groups)), dim3(256), 0, (hipStream_t)stream, p);
+    return launch_status();
+}
+
+int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
+    LGCN_CHECK_PTR(ph);
+    const lgcn_laneconv_t &q = *ph;
+    if (!lc_mma_ok(q.mma)) return LGCN_ESHAPE;
+    int Ms, Ml, caps, capl;
+    lc_cfg(q.mma, 0, &Ms, &caps);
+    lc_cfg(q.mma, 1, &Ml, &capl);
+    const int M = q.rows_per_block;
+    if (q.n_rows < 0 || (M != Ms && M != Ml) || q.cap < M || q.cap > (M == Ml ? capl : caps) || q.n_rows > 0x7fffffff) return LGCN_EINVAL;
+    if (!lc_groups_ok(q.n_units, q.n_groups, q.gstart)) return LGCN_EINVAL;
+    if (q.n_rows == 0) return LGCN_OK;
+    const void *ptrs[] = {q.x, q.plan, q.out, q.wp2, q.gn1_g, q.gn1_b, q.gn2_g, q.gn2_b};
+    for (const void *v : ptrs) { LGCN_CHECK_PTR(v); LGCN_CHECK_ALIGN16(v); }
+    if (q.n_groups > 1) { LGCN_CHECK_PTR(q.part); LGCN_CHECK_ALIGN16(q.part); }
+    if (q.n_units > 1) LGCN_CHECK_PTR(q.col);
+    for (int u = 0; u < q.n_units; ++u)
+        if (q.wp[u]) LGCN_CHECK_ALIGN16(q.wp[u]);
+    LGCN_CHECK_PTR(q.wp[0]);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n_blocks = (q.n_rows + M - 1) / M;
+    LcTileParams t;
+    t.x = q.x; t.n_rows = q.n_rows;
+    for (int u = 0; u < kLcUnits; ++u) t.wp[u] = u < q.n_units ? q.wp[u] : nullptr;
+    t.col = q.col; t.plan = q.plan; t.n_blocks = (int)n_blocks; t.n_groups = q.n_groups; t.cap = q.cap;
+    for (int g = 0; g <= q.n_groups; ++g) t.gstart[g] = q.gstart[g];
+    for (int g = q.n_groups + 1; g < kLcUnits + 2; ++g) t.gstart[g] = q.gstart[q.n_groups];
+    t.part = q.part;
+    t.wp2 = q.wp2; t.gn1_g = q.gn1_g; t.gn1_b = q.gn1_b; t.gn2_g = q.gn2_g; t.gn2_b = q.gn2_b; t.eps = q.eps; t.out = q.out;
+    t.stamps = nullptr;
+#ifdef LGCN_STAMPS
+    t.stamps = g_lc_stamps;
+#endif
+    LcCombParams c{q.part, q.n_rows, M, q.n_groups, q.x, q.wp2, q.gn1_g, q.gn1_b, q.gn2_g, q.gn2_b, q.eps, q.out};
+    const unsigned grid1 = (unsigned)(n_blocks * q.n_groups);
+    const int n_tiles = (int)((q.n_rows + 31) / 32);
+    const bool tall = M == Ml;
+#define LGCN_LC(F_)                                                                                          \
+    do {                                                                                                     \
+        if (q.n_groups == 1) {                                                                               \
+            if (tall) hipLaunchKernelGGL((k_lc_tile<F_, 1, true>), dim3(grid1), dim3(512), 0, st, t);         \
+            else hipLaunchKernelGGL((k_lc_tile<F_, 0, true>), dim3(grid1), dim3(512), 0, st, t);              \
+        } else {                                                                                             \
+            if (tall) hipLaunchKernelGGL((k_lc_tile<F_, 1, false>), dim3(grid1), dim3(512), 0, st, t);        \
+            else hipLaunchKernelGGL((k_lc_tile<F_, 0, false>), dim3(grid1), dim3(512), 0, st, t);             \
+            hipLaunchKernelGGL((k_lc_combine<F_>), dim3(n_tiles), dim3(256), 0, st, c, n_tiles);             \
+        }                                                                                                    \
+    } while (0)
+    switch (fmt_of(q.mma)) {
+        case 0: LGCN_LC(0); break;
+        case 1: LGCN_LC(1); break;
+        default: LGCN_LC(2); break;
+    }
+#undef LGCN_LC
+    return launch_status();
+}
+
+}  // extern "C"

@@ -8,7 +8,7 @@ synchronisation and no data-dependent host control flow, so the whole forward ca
 a hipGraph (``capture``) and replayed with one host call.
 """
 from dataclasses import dataclass
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import numpy as np
 import torch
@@ -117,10 +117,14 @@ class HotPathEngine:
     """graph_gather -> MapNet -> A2M -> M2M -> M2A -> A2A on the HIP kernels, sync-free."""
 
     def __init__(self, map_net: M.MapNet, a2m: M.A2M, m2m: M.M2M, m2a: M.M2A, a2a: M.A2A, config=None,
-                 legacy_offsets: bool = True, branches: bool = False):
+                 legacy_offsets: bool = True, branches: bool = False, lane_impl: Optional[str] = None):
         self.map_net, self.a2m, self.m2m, self.m2a, self.a2a = map_net, a2m, m2m, m2a, a2a
         self.config = config or M.config
         self.legacy_offsets = legacy_offsets
+        # LaneConv implementation (lanegcn.lane_conv): None = the package default ("tiled": weight-stationary row
+        # blocks, the faster one for ONE forward at a time); "fused" = one elastic launch per layer, which packs
+        # better when several captured forwards share the GPU (bench.py --streams > 1; DESIGN.md section 4)
+        self.lane_impl = lane_impl
         # optional parallel graph branches: the three pair searches (index work that depends only on the centres)
         # and every Att's V GEMM on a side stream, forked / joined with events (captured as graph edges).
         # Measured on MI355X / ROCm 7.2: bitwise the same result, no single-stream gain (38.9 k vs 39.4 k
@@ -137,7 +141,8 @@ class HotPathEngine:
             g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
             plan = ops.csr_build([g64[a:b] for (a, b), _ in fb.rel_slices], [g64[a:b] for _, (a, b) in fb.rel_slices],
                                  fb.n_nodes)
-            feat = M.lane_conv(self.map_net.fuse, self.map_net.stem(fb.node_ctrs, fb.node_feats), plan, fb.num_scales)
+            feat = M.lane_conv(self.map_net.fuse, self.map_net.stem(fb.node_ctrs, fb.node_feats), plan, fb.num_scales,
+                               impl=self.lane_impl)
             return {"nodes": feat, "actors": actors}
         cfg = self.config
         out = {}
@@ -163,7 +168,7 @@ class HotPathEngine:
         plan = ops.csr_build(us, vs, fb.n_nodes)
         # MapNet (lanegcn.py:311-363)
         feat = self.map_net.stem(fb.node_ctrs, fb.node_feats)
-        feat = M.lane_conv(self.map_net.fuse, feat, plan, fb.num_scales)
+        feat = M.lane_conv(self.map_net.fuse, feat, plan, fb.num_scales, impl=self.lane_impl)
         if stages:
             out["map_net"] = feat
         # A2M (lanegcn.py:385-407)
@@ -175,7 +180,7 @@ class HotPathEngine:
         if stages:
             out["a2m"] = feat
         # M2M (lanegcn.py:445-480)
-        feat = M.lane_conv(self.m2m.fuse, feat, plan, fb.num_scales)
+        feat = M.lane_conv(self.m2m.fuse, feat, plan, fb.num_scales, impl=self.lane_impl)
         if stages:
             out["m2m"] = feat
         # M2A (lanegcn.py:502-513)
@@ -211,7 +216,7 @@ class HotPathEngine:
 
         def map_net():
             st["nodes"] = M.lane_conv(self.map_net.fuse, self.map_net.stem(fb.node_ctrs, fb.node_feats), st["plan"],
-                                      fb.num_scales)
+                                      fb.num_scales, impl=self.lane_impl)
 
         def a2m():
             feat = self.a2m.fuse_meta(st["nodes"], fb.turn, fb.control, fb.intersect)
@@ -220,7 +225,7 @@ class HotPathEngine:
             st["nodes_a2m"] = feat
 
         def m2m():
-            st["nodes_m2m"] = M.lane_conv(self.m2m.fuse, st["nodes_a2m"], st["plan"], fb.num_scales)
+            st["nodes_m2m"] = M.lane_conv(self.m2m.fuse, st["nodes_a2m"], st["plan"], fb.num_scales, impl=self.lane_impl)
 
         def m2a():
             act = actors

@@ -223,9 +223,24 @@ def _fuse_modules(n_map: int, num_scales: int, ng: int = 1) -> nn.ModuleDict:
     return nn.ModuleDict(fuse)
 
 
-def lane_conv(fuse: nn.ModuleDict, feat: Tensor, plan: ops.LanePlan, num_scales: int, tile_rb: int = 0) -> Tensor:
-    """4 LaneConv layers, one fused launch each (reference lanegcn.py:331-362 == 448-479)."""
+def lane_conv(fuse: nn.ModuleDict, feat: Tensor, plan: ops.LanePlan, num_scales: int, tile_rb: int = 0,
+              impl: Optional[str] = None) -> Tensor:
+    """4 LaneConv layers (reference lanegcn.py:331-362 == 448-479).
+    impl "tiled" (default in the split-precision matrix modes): lgcn_laneconv_fwd, weight-stationary row blocks
+    over LDS-resident source rows + a combine launch; "fused": one lgcn_agg_mlp launch per layer (the only
+    implementation of the exact-f32 mode, and the one the autograd path records)."""
     keys = rel_keys(num_scales)
+    impl = impl or ops.laneconv_impl()
+    lcp = ops.lc_plan(plan) if impl == "tiled" and tile_rb == 0 and plan.n_nodes > 0 else None
+    if lcp is not None:
+        part = ops.lc_part(lcp)
+        for i in range(len(fuse["ctr"])):
+            wps = [ops.packed(fuse["ctr"][i].weight)]
+            wps += [ops.packed(fuse[key][i].weight) if plan.n_edges[r] > 0 else None for r, key in enumerate(keys)]
+            c2 = fuse["ctr2"][i]
+            feat = ops.laneconv_fwd(feat, lcp, wps, _gn(fuse["norm"][i]), ops.packed(c2.linear.weight), _gn(c2.norm),
+                                    eps=fuse["norm"][i].eps, part=part)
+        return feat
     for i in range(len(fuse["ctr"])):
         rels = [ops.RelSpec(feat, ops.packed(fuse["ctr"][i].weight), L.REL_IDENT)]
         for r, key in enumerate(keys):

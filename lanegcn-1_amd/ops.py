@@ -467,6 +467,155 @@ def agg_mlp_pair(a: dict, b: dict, tag=None):
     return oa, ob
 
 
+# ------------------------------------------------------------------ LaneConv (gather-free, weight-stationary)
+@dataclass
+class LcPlan:
+    """Work-item plan of lgcn_laneconv_fwd for one lane graph and one row-block geometry (include/lgcn.h)."""
+    plan: torch.Tensor            # int32 words (lgcn_lc_plan_build)
+    lane: LanePlan
+    rows_per_block: int
+    cap: int
+    n_units: int
+    gstart: List[int]             # unit groups: one workgroup per (row block, group)
+
+
+def lc_config(mma: Optional[int] = None, variant: int = 0):
+    """(rows_per_block, LDS source-row capacity) of a matrix mode (variant 0: short row block, 1: tall);
+    None for LGCN_MMA_F32 (lgcn_agg_mlp path)."""
+    lib = L.load()
+    mma = _mma if mma is None else mma
+    if mma == L.MMA_F32:
+        return None
+    m, c = C.c_int32(), C.c_int32()
+    L.check(lib.lgcn_lc_config(mma, variant, C.byref(m), C.byref(c)), "lgcn_lc_config")
+    return m.value, c.value
+
+
+def lc_groups(n_units: int, n_groups: int) -> List[int]:
+    """Consecutive, near-equal unit groups: [0, ..., n_units]."""
+    n_groups = max(1, min(n_groups, n_units))
+    return [(g * n_units + n_groups - 1) // n_groups for g in range(n_groups)] + [n_units]
+
+
+_cu_cache = {}
+
+
+def cu_count(device) -> int:
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    if idx not in _cu_cache:
+        _cu_cache[idx] = torch.cuda.get_device_properties(idx).multi_processor_count
+    return _cu_cache[idx]
+
+
+_lc_groups_forced = int(os.environ.get("LGCN_LC_GROUPS", "0"))
+_lc_variant_forced = int(os.environ.get("LGCN_LC_VARIANT", "-1"))
+
+
+def set_lc_variant(v: int):
+    """Force the row-block height of subsequently built LaneConv plans (0 short, 1 tall, -1 = pick by size)."""
+    global _lc_variant_forced
+    _lc_variant_forced = int(v)
+
+_lc_impl = os.environ.get("LGCN_LANECONV", "tiled")
+
+
+def set_laneconv_impl(name: str):
+    """"tiled" (lgcn_laneconv_fwd) or "fused" (one lgcn_agg_mlp launch per layer) for inference LaneConv layers."""
+    global _lc_impl
+    if name not in ("tiled", "fused"):
+        raise L.LgcnError("laneconv impl must be 'tiled' or 'fused'")
+    _lc_impl = name
+
+
+def laneconv_impl() -> str:
+    return _lc_impl
+
+
+def set_lc_groups(n: int):
+    """Force the number of unit groups of subsequently built LaneConv plans (0 = pick by CU count)."""
+    global _lc_groups_forced
+    _lc_groups_forced = int(n)
+
+
+def lc_plan(lane: LanePlan, n_groups: Optional[int] = None, cap: Optional[int] = None,
+            variant: Optional[int] = None) -> Optional[LcPlan]:
+    """LaneConv work-item plan for the current matrix mode, built once per lane graph and cached on it.
+    variant: 0 = short row blocks, 1 = tall (default: tall once there are two row blocks per CU).
+    n_groups: unit groups per row block (default 1: one launch per layer, no partial sums; more groups buy
+    parallelism for a single small forward at the price of a second launch)."""
+    if lc_config() is None:
+        return None
+    lib = L.load()
+    if variant is None:
+        variant = _lc_variant_forced
+    if variant is None or variant < 0:
+        m_tall, _ = lc_config(variant=1)
+        variant = 1 if (lane.n_nodes + m_tall - 1) // m_tall >= 2 * cu_count(lane.rowptr.device) else 0
+    M, cap_max = lc_config(variant=variant)
+    cap = cap_max if cap is None else cap
+    n_units = lane.n_rel + 1
+    if n_groups is None:
+        # one group (one launch per layer, no partial sums) once the row blocks alone fill the chip; small batches
+        # buy parallelism with unit groups (S2, 108 short row blocks on 256 CUs: two groups)
+        n_blocks = (lane.n_nodes + M - 1) // M
+        n_groups = _lc_groups_forced if _lc_groups_forced > 0 else max(1, min(4, round(cu_count(lane.rowptr.device) / max(n_blocks, 1))))
+    gstart = lc_groups(n_units, n_groups)
+    cache = lane.__dict__.setdefault("_lc", {})
+    key = (M, cap, tuple(gstart))
+    hit = cache.get(key)
+    if hit is not None:
+        return hit
+    n_words = lib.lgcn_lc_plan_elems(lane.n_nodes, M, cap)
+    if n_words < 0:
+        raise L.LgcnError("lc_plan: bad geometry (n_nodes=%d, M=%d, cap=%d)" % (lane.n_nodes, M, cap))
+    plan = torch.empty(max(n_words, 4), dtype=torch.int32, device=lane.rowptr.device)
+    gs = (C.c_int32 * len(gstart))(*gstart)
+    L.check(lib.lgcn_lc_plan_build(_ptr(lane.rowptr), _ptr(lane.col), lane.n_nodes, lane.n_rel, M, cap,
+                                   len(gstart) - 1, gs, _ptr(plan), _stream()), "lgcn_lc_plan_build")
+    out = LcPlan(plan, lane, M, cap, n_units, gstart)
+    cache[key] = out
+    return out
+
+
+def lc_part(lcp: LcPlan) -> Optional[torch.Tensor]:
+    """Partial-sum workspace of lgcn_laneconv_fwd (may be shared by consecutive layers on one stream); None for
+    single-group plans, which need none."""
+    lib = L.load()
+    n = lib.lgcn_lc_part_elems(lcp.lane.n_nodes, lcp.rows_per_block, len(lcp.gstart) - 1)
+    if n <= 0:
+        return None
+    return torch.empty(n, dtype=torch.float32, device=lcp.plan.device)
+
+
+def laneconv_fwd(x: torch.Tensor, lcp: LcPlan, wps: Sequence[Optional[torch.Tensor]], gn1, wp2, gn2, eps=EPS,
+                 part: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tag="laneconv"):
+    """One LaneConv layer (lgcn_laneconv_fwd): wps[u] = packed weight of unit u (ctr, then the plan's relations;
+    None for a relation without edges)."""
+    lib = L.load()
+    x = _dev(x, torch.float32, "x")
+    if x.shape[0] != lcp.lane.n_nodes or len(wps) != lcp.n_units:
+        raise L.LgcnError("laneconv_fwd: x / weights do not match the plan")
+    p = L.LaneConv()
+    p.n_rows, p.x = x.shape[0], x.data_ptr()
+    for u, w in enumerate(wps):
+        p.wp[u] = 0 if w is None else w.data_ptr()
+    p.col, p.plan = lcp.lane.col.data_ptr(), lcp.plan.data_ptr()
+    p.rows_per_block, p.cap, p.n_units, p.n_groups = lcp.rows_per_block, lcp.cap, lcp.n_units, len(lcp.gstart) - 1
+    for g, v in enumerate(lcp.gstart):
+        p.gstart[g] = v
+    p.gn1_g, p.gn1_b, p.wp2, p.gn2_g, p.gn2_b = gn1[0].data_ptr(), gn1[1].data_ptr(), wp2.data_ptr(), gn2[0].data_ptr(), gn2[1].data_ptr()
+    p.eps, p.mma = eps, _mma
+    if part is None:
+        part = lc_part(lcp)
+    if out is None:
+        out = torch.empty_like(x)
+    p.part, p.out = (0 if part is None else part.data_ptr()), out.data_ptr()
+    with _Timed(tag):
+        L.check(lib.lgcn_laneconv_fwd(C.byref(p), _stream()), "lgcn_laneconv_fwd")
+    return out
+
+
 def mapnet_input(ctrs, feats, wa1, ba1, wpa2, gn_a, ws1, bs1, wps2, gn_s, eps=EPS):
     lib = L.load()
     ctrs = _dev(ctrs, torch.float32, "ctrs")
