@@ -402,6 +402,16 @@ int lgcn_pair_add(const float *c, const float *U, const int32_t *hi, const float
 int lgcn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev, int64_t cap,
                      float *out, void *stream);
 
+/*
+ * Range check of the 16-bit-plane matrix modes.  LGCN_MMA_F16X2 operands must stay below fp16's 65504 (BF16X3 / BF16:
+ * bf16's 3.4e38); an operand beyond that becomes +-inf planes, whose products cancel to NaN, and every ReLU of this
+ * library keeps a NaN a NaN (like ATen's), so the row it belongs to -- and every row fed by it -- reaches the stage
+ * output as NaN rather than as plausible numbers.  lgcn_check_finite looks for that on the device:
+ *   flag[0] |= bit  if any of a[0..na) or b[0..nb) is not finite   (na, nb multiples of 4; flag zeroed by the caller).
+ * The host side reads the flag once per forward and re-runs a flagged forward in LGCN_MMA_BF16X3 (ops.py: guarded).
+ */
+int lgcn_check_finite(const float *a, int64_t na, const float *b, int64_t nb, int32_t *flag, int bit, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

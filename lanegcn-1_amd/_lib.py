@@ -91,6 +91,7 @@ SIGNATURES = {
     "lgcn_gather_rows": (C.c_int, [_P, _P, _P, _L, _P, _P]),
     "lgcn_gather_sum": (C.c_int, [_P, _P, _P, _L, _P, _P]),
     "lgcn_pair_add": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "lgcn_check_finite": (C.c_int, [_P, _L, _P, _L, _P, _I, _P]),
     "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
     "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
 }

@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_gn_cl(const float *__restrict__ x, int6
             const float up = (t & 1) ? 0.75f * mid + 0.25f * nb : 0.25f * nb + 0.75f * mid;
             v = up + v;
         } else if (ri) v += ri[i];
-        if (relu) v = fmaxf(v, 0.f);
+        if (relu) v = relu_nan(v);
         oi[i] = v;
     }
 }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_gn_cl_vec(const float *__restrict__ x, 
         y.z = (v[k].z - mean) * rstd * g4.z + b4.z; y.w = (v[k].w - mean) * rstd * g4.w + b4.w;
         if (ri && res_up2) { y.x = r4.x + y.x; y.y = r4.y + y.y; y.z = r4.z + y.z; y.w = r4.w + y.w; }
         else if (ri) { y.x += r4.x; y.y += r4.y; y.z += r4.z; y.w += r4.w; }
-        if (relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        if (relu) { y.x = relu_nan(y.x); y.y = relu_nan(y.y); y.z = relu_nan(y.z); y.w = relu_nan(y.w); }
         oi[j] = y;
     }
 }
@@ -329,6 +329,23 @@ __global__ __launch_bounds__(256) void k_pair_add(const float4 *__restrict__ c, 
     const int l = threadIdx.x & 31;
     for (int64_t i = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5); i < n; i += (int64_t)gridDim.x * 8)
         out[i * 32 + l] = f4add(f4add(c[i * 32 + l], U[(int64_t)hi[i] * 32 + l]), V[(int64_t)wi[i] * 32 + l]);
+}
+
+// Any element of x not finite -> flag[0] |= bit (integer atomic, only when something is found).  Up to two
+// tensors per launch.  The 16-bit-plane matrix modes have fp16's / bf16's range: an overflow shows up as NaN rows
+// in the stage outputs (the kernels' ReLU keeps NaN), this is how a caller looks for them without a device->host
+// copy of the features.
+__global__ __launch_bounds__(256) void k_check_finite(const float4 *__restrict__ a, int64_t na4, const float4 *__restrict__ b,
+                                                      int64_t nb4, int32_t *flag, int bit) {
+    bool bad = false;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na4 + nb4; i += stride) {
+        const float4 v = i < na4 ? a[i] : b[i - na4];
+        // finite <=> exponent field below all-ones: (v - v) is 0 for finite v and NaN otherwise
+        const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
+        bad |= !(t == 0.f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
 }
 
 }  // namespace lgcn
@@ -445,6 +462,19 @@ int lgcn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev,
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_gather_rows, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4 *>(src), idx, n_dev, cap, reinterpret_cast<float4 *>(out));
+    return launch_status();
+}
+
+int lgcn_check_finite(const float *a, int64_t na, const float *b, int64_t nb, int32_t *flag, int bit, void *stream) {
+    if (na < 0 || nb < 0 || (na & 3) || (nb & 3) || bit == 0) return LGCN_EINVAL;
+    if (na + nb == 0) return LGCN_OK;
+    LGCN_CHECK_PTR(flag);
+    if (na) { LGCN_CHECK_PTR(a); LGCN_CHECK_ALIGN16(a); }
+    if (nb) { LGCN_CHECK_PTR(b); LGCN_CHECK_ALIGN16(b); }
+    int64_t blocks = ((na + nb) / 4 + 1023) / 1024;      // four float4 per thread
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_check_finite, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4 *>(a), na / 4, reinterpret_cast<const float4 *>(b), nb / 4, flag, bit);
     return launch_status();
 }
 

@@ -17,6 +17,12 @@ using f32x16 = float __attribute__((ext_vector_type(16)));
 #define LGCN_CHECK_PTR(p) do { if ((p) == nullptr) return LGCN_EINVAL; } while (0)
 #define LGCN_CHECK_ALIGN16(p) do { if ((reinterpret_cast<uintptr_t>(p) & 15u) != 0) return LGCN_EALIGN; } while (0)
 
+// ReLU that keeps a NaN a NaN, like ATen's relu / clamp_min (v_max_f32 -- fmaxf -- returns the other operand):
+// an overflow of the 16-bit operand planes (inf - inf) or a NaN in the input must reach the output, where the
+// caller can see it, instead of being clamped to a plausible-looking zero on the way.  gfx950 has the IEEE 754-2019
+// maximum as one instruction (v_maximum3_f32).
+__device__ __forceinline__ float relu_nan(float x) { return __builtin_elementwise_maximum(x, 0.f); }
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LGCN_OK : static_cast<int>(e);

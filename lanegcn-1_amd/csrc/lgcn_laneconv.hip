@@ -323,7 +323,10 @@ void k_lc_tile(const LcTileParams p) {
             load_w_ks(p.wp[uf], wc, 1);
             load_loc(uf, lc);
         }
-        if (tid < ROWB / 16) reinterpret_cast<uint4 *>(smem + CAP * ROWB)[tid] = make_uint4(0, 0, 0, 0);
+        // the zero row and (below) the unit list are written by EVERY thread, redundantly, rather than by the first
+        // few lanes of wave 0: with partial-exec regions in this prologue the register allocator's spill reloads
+        // (this kernel runs at its VGPR limit) left the inactive lanes of wave 0 with stale values further down
+        reinterpret_cast<uint4 *>(smem + CAP * ROWB)[tid % (ROWB / 16)] = make_uint4(0, 0, 0, 0);
         {
             // the opaque zero keeps the loader's per-row addressing (invariant across items) out of the loop
             // pre-header, where the hoisted values would sit in registers / scratch for the whole kernel
@@ -364,9 +367,10 @@ void k_lc_tile(const LcTileParams p) {
                     if (h0 + j < NIT && e[h0 + j].y >= 0) lc_split_store<F>(smem, (h0 + j) * 16 + hw, l, v[j]);
             }
         }
-        if (tid < 16) {
-            const int w = (tid >> 2) == 0 ? hu.x : (tid >> 2) == 1 ? hu.y : (tid >> 2) == 2 ? hu.z : hu.w;
-            s_ul[tid] = (w >> (8 * (tid & 3))) & 0xff;
+        {
+            const int t16 = tid & 15;
+            const int w = (t16 >> 2) == 0 ? hu.x : (t16 >> 2) == 1 ? hu.y : (t16 >> 2) == 2 ? hu.z : hu.w;
+            s_ul[t16] = (w >> (8 * (t16 & 3))) & 0xff;
         }
         if (!DBUF) {      // shared shape: requested behind the row loads; arrives under the barrier / the other workgroup
             load_w_ks(p.wp[uf], wc, 0);
@@ -554,8 +558,6 @@ __global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_
     const int b = (int)(row0 / p.M), rib0 = (int)(row0 % p.M);
     const uint4 *wp2 = reinterpret_cast<const uint4 *>(p.wp2);
 
-    BPair<F> bf;
-    ring_prime<F>(bf, wp2, wave, lane);
     const int row = tid >> 3;
     const int64_t n = row0 + row;
     const bool live_row = n < p.n_rows;
@@ -593,7 +595,11 @@ __global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_
     __syncthreads();
     f32x4 acc[2][2];
     acc_zero<2>(acc);
-    gemm_pass<2, F>(A, wp2, nullptr, bf, wave, lane, acc);
+    {
+        BPair<F> bf;
+        ring_prime<F>(bf, wp2, wave, lane);
+        gemm_pass<2, F>(A, wp2, nullptr, bf, wave, lane, acc);
+    }
     acc_store<2>(T, acc, lane, wave);
     __syncthreads();
     r = row_load(T, tid);

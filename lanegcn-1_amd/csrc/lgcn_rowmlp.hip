@@ -250,10 +250,10 @@ __device__ __forceinline__ void lin2_relu_to_lds(float *T, int t, float x, float
         const float4 wb = *reinterpret_cast<const float4 *>(w1 + 2 * c + 4);  // c+2, c+3
         const float4 bb = *reinterpret_cast<const float4 *>(b1 + c);
         float4 o;
-        o.x = fmaxf(x * wa.x + y * wa.y + bb.x, 0.f);
-        o.y = fmaxf(x * wa.z + y * wa.w + bb.y, 0.f);
-        o.z = fmaxf(x * wb.x + y * wb.y + bb.z, 0.f);
-        o.w = fmaxf(x * wb.z + y * wb.w + bb.w, 0.f);
+        o.x = relu_nan(x * wa.x + y * wa.y + bb.x);
+        o.y = relu_nan(x * wa.z + y * wa.w + bb.y);
+        o.z = relu_nan(x * wb.x + y * wb.y + bb.z);
+        o.w = relu_nan(x * wb.z + y * wb.w + bb.w);
         *reinterpret_cast<float4 *>(p + 32 * j) = o;
     }
 }
@@ -509,6 +509,12 @@ int lgcn_pack_weight_batch(const lgcn_pack_job_t *jobs, int n_jobs, int mma, voi
 
 static int validate_agg(const lgcn_agg_mlp_t &p, bool *need_col_out) {
     if (p.n_rows < 0 || p.n_rel < 1 || p.n_rel > LGCN_MAX_REL || !valid_mma(p.mma)) return LGCN_EINVAL;
+    constexpr int kKnownFlags = LGCN_F_GN1 | LGCN_F_RELU1 | LGCN_F_GEMM2 | LGCN_F_GN2 | LGCN_F_RES | LGCN_F_RELU2;
+#ifdef LGCN_ABLATE
+    if (p.flags & ~(kKnownFlags | (1 << 8) | (1 << 9))) return LGCN_EINVAL;
+#else
+    if (p.flags & ~kKnownFlags) return LGCN_EINVAL;      // unknown bits are an error, not a silent no-op
+#endif
     if (p.n_rows == 0) return LGCN_OK;
     if (p.n_rows > 0x7fffffff) return LGCN_ESHAPE;
     LGCN_CHECK_PTR(p.out); LGCN_CHECK_ALIGN16(p.out);

@@ -359,12 +359,19 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
         uint16_t *cur = (i & 1) ? buf1 : buf0;
         uint16_t *nxt = (i & 1) ? buf0 : buf1;
         if (wave < 4) {
-            if (!(flags & (1 << 9))) {   // timing-only ablation bit (tools/bench_agg.py): skip the MFMA passes
+#ifdef LGCN_ABLATE   // diagnostic build only (make ablate, tools/bench_agg.py): flag bit 9 skips the MFMA passes
+            if (!(flags & (1 << 9)))
+#endif
+            {
             const float *wn = i + 1 < nact ? p.rel[rel_at(i + 1)].wp : (two ? p.wp2 : nullptr);
             gemm_pass<RB, F>(cur, reinterpret_cast<const uint4 *>(p.rel[rel_at(i)].wp),
                               reinterpret_cast<const uint4 *>(wn), bfrag, wave, lane, acc);
             }
-        } else if (i + 1 < nact && !(flags & (1 << 8))) {   // ablation bit: skip the in-loop gathers
+        } else if (i + 1 < nact
+#ifdef LGCN_ABLATE   // diagnostic build only: flag bit 8 skips the in-loop gathers
+                   && !(flags & (1 << 8))
+#endif
+        ) {
             gather(nxt, rel_at(i + 1));
         }
         LGCN_STAMP(4 + 2 * i);       // own work of pass i done
@@ -489,10 +496,10 @@ __device__ __forceinline__ void lin2_relu_split(uint16_t *planes, int plane_elem
         const float4 wb = *reinterpret_cast<const float4 *>(w1 + 2 * c + 4);
         const float4 bb = *reinterpret_cast<const float4 *>(b1 + c);
         float4 o;
-        o.x = fmaxf(x * wa.x + y * wa.y + bb.x, 0.f);
-        o.y = fmaxf(x * wa.z + y * wa.w + bb.y, 0.f);
-        o.z = fmaxf(x * wb.x + y * wb.y + bb.z, 0.f);
-        o.w = fmaxf(x * wb.z + y * wb.w + bb.w, 0.f);
+        o.x = relu_nan(x * wa.x + y * wa.y + bb.x);
+        o.y = relu_nan(x * wa.z + y * wa.w + bb.y);
+        o.z = relu_nan(x * wb.x + y * wb.y + bb.z);
+        o.w = relu_nan(x * wb.z + y * wb.w + bb.w);
         split_store<F>(planes, plane_elems, row, c, o);
     }
 }
@@ -625,17 +632,14 @@ __global__ __launch_bounds__(256) void k_att_pairs_bf(const PairParams p) {
 }
 
 // ------------------------------------------------------------ dispatch -----
+// CUs of the current device, asked per call: the library keeps no state, not even a cache (the query is a
+// table lookup in the runtime, ~0.1 us, against launches of >= 5 us).
 static int cu_count() {
-    static int n = 0;   // read-only cache of a device attribute
-    if (n == 0) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-            n = v;
-        else
-            n = 256;
-    }
-    return n;
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+        return v;
+    return 256;
 }
 
 // 16-row blocks per tile.  Tiles of <= 32 rows (<= 128 VGPRs, <= 63 KB LDS) and, in the two-plane / one-plane modes,
@@ -661,11 +665,17 @@ static int pick_rb(int64_t n_rows, int fmt, bool lane_conv = false) {
     return best;
 }
 
-// Tuning knobs for experiments (read once): LGCN_RB forces the tile height, LGCN_RING=1|3 the weight
-// prefetch distance.  Defaults: height by pick_rb, distance 1.
+// Tuning knobs of the diagnostic builds (-DLGCN_TUNING: make stamps / ablate), read from the environment once:
+// LGCN_RB / LGCN_RB_LC force the tile height, LGCN_RING=3 the deep weight ring, LGCN_EXP_PAD_LDS pads the LaneConv
+// workgroups with dynamic LDS.  The shipped library reads no environment variable.
 static int env_int(const char *name, int dflt) {
+#ifdef LGCN_TUNING
     const char *v = std::getenv(name);
     return v && *v ? std::atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 template <int F, bool DEEP>

@@ -70,8 +70,8 @@ __device__ __forceinline__ void row_gn(RowVals &r, int t, const float *__restric
 __device__ __forceinline__ void row_relu(RowVals &r) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        r.v[j].x = fmaxf(r.v[j].x, 0.f); r.v[j].y = fmaxf(r.v[j].y, 0.f);
-        r.v[j].z = fmaxf(r.v[j].z, 0.f); r.v[j].w = fmaxf(r.v[j].w, 0.f);
+        r.v[j].x = relu_nan(r.v[j].x); r.v[j].y = relu_nan(r.v[j].y);
+        r.v[j].z = relu_nan(r.v[j].z); r.v[j].w = relu_nan(r.v[j].w);
     }
 }
 

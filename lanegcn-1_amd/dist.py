@@ -79,15 +79,25 @@ def broadcast_parameters(tensors: Iterable[torch.Tensor], src: int = 0):
 
 def allreduce_mean_grads(params: Iterable[torch.nn.Parameter]):
     """Average gradients over ranks (Horovod DistributedOptimizer semantics, train.py:66-69) with one
-    all-reduce over a single flat fp32 bucket (14.8 MB for the full net)."""
-    ps = [p for p in params if p.grad is not None]
+    all-reduce over a single flat fp32 bucket (14.8 MB for the full net).
+
+    The bucket covers EVERY parameter that requires grad, in parameter order, zeros standing in for a gradient
+    this rank does not have: which parameters receive a gradient depends on the rank's batch (a relation without
+    edges skips its weights, lanegcn.py:343-354; an Att block without context skips dist / query / ctx, :664-670),
+    and ranks that disagreed on the bucket's length would hang or corrupt the collective.  Afterwards every such
+    parameter holds the average (Horovod averages zeros in the same way)."""
+    ps = [p for p in params if p.requires_grad]
     if not is_on() or not ps:
         return
-    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).float() for p in ps])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     flat.div_(dist.get_world_size())
     off = 0
     for p in ps:
         n = p.numel()
-        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        g = flat[off:off + n].view_as(p)
+        if p.grad is None:
+            p.grad = g.to(p.dtype).clone()
+        else:
+            p.grad.copy_(g)
         off += n

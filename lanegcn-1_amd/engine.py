@@ -196,7 +196,23 @@ class HotPathEngine:
             out["a2a"] = act
         out["nodes"], out["actors"] = feat, act
         out["n_pairs"] = [p.n_pairs for p in pairs]
+        # range check of the 16-bit-plane modes, on the device and part of every (captured) forward: bit 0 of
+        # out["nonfinite"] is set when a feature row came out NaN / inf (ops.guarded / forward_guarded act on it)
+        flag = torch.zeros(1, dtype=torch.int32, device=feat.device)
+        ops.check_finite(flag, feat, act)
+        out["nonfinite"] = flag
         return out
+
+    def forward_guarded(self, fb: FlatBatch, actors: torch.Tensor, **kw) -> Dict[str, torch.Tensor]:
+        """forward() + the host side of the range guard: reads the flag (one 4-byte device->host copy) and re-runs an
+        f16x2 forward that left fp16's range in bf16x3, or raises, as ops.set_guard() says."""
+        out = self.forward(fb, actors, **kw)
+        if ops.get_guard() == "off" or ops.get_mma() != "f16x2" or int(out["nonfinite"].item()) == 0:
+            return out
+        if ops.get_guard() == "raise":
+            raise ops.L.LgcnError("non-finite features in f16x2 mode: an operand left fp16's range (|x| >= 65504)")
+        with ops.mma_scope("bf16x3"):
+            return self.forward(fb, actors, **kw)
 
     @torch.no_grad()
     def stage_functions(self, fb: FlatBatch, actors: torch.Tensor):
@@ -295,7 +311,8 @@ class FullNetEngine:
         reg = torch.cat(out["reg"], 0)
         cls = torch.cat(out["cls"], 0)
         reg = torch.einsum("amtk,akj->amtj", reg, rot) + orig.view(-1, 1, 1, 2)
-        res = {"cls": cls, "reg": reg}
+        res = {"cls": cls, "reg": reg, "nonfinite": hot["nonfinite"]}
+        ops.check_finite(hot["nonfinite"], reg.reshape(-1), cls.reshape(-1), bit=2)      # PredNet's row blocks too
         if return_pairs:
             res["n_pairs"] = hot["n_pairs"]     # device counts of the three pair sets (A2M, M2A, A2A)
         return res

@@ -287,8 +287,7 @@ class MapNet(nn.Module):
             fs = A.linear_gn(F.relu(s[0](graph["feats"])), s[2].linear.weight, gn=s[2].norm)
             feat = lane_conv_train(self.fuse, F.relu(fa + fs), lane_plan(graph), lane_plan_t(graph), len(graph["pre"]))
             return feat, graph["idcs"], graph["ctrs"]
-        feat = self.stem(ctrs, graph["feats"])
-        feat = lane_conv(self.fuse, feat, lane_plan(graph), len(graph["pre"]))
+        feat = ops.guarded(lambda: lane_conv(self.fuse, self.stem(ctrs, graph["feats"]), lane_plan(graph), len(graph["pre"])))
         return feat, graph["idcs"], graph["ctrs"]
 
 
@@ -304,7 +303,7 @@ class M2M(nn.Module):
     def forward(self, feat: Tensor, graph: Dict) -> Tensor:
         if _hot_guard(feat, *ops.module_params(self)):
             return lane_conv_train(self.fuse, feat, lane_plan(graph), lane_plan_t(graph), len(graph["pre"]))
-        return lane_conv(self.fuse, feat, lane_plan(graph), len(graph["pre"]))
+        return ops.guarded(lambda: lane_conv(self.fuse, feat, lane_plan(graph), len(graph["pre"])))
 
 
 # ------------------------------------------------------------------ attention blocks
@@ -353,14 +352,15 @@ class Att(nn.Module):
             if train:
                 a = A.linear_gn(agts, self.agt.weight, relu=True)
                 return A.linear_gn(a, lin.linear.weight, gn=lin.norm, relu=True, res=agts)
-            return ops.agg_mlp(T, [ops.RelSpec(agts, ops.packed(self.agt.weight))],
-                               L.F_RELU1 | L.F_GEMM2 | L.F_GN2 | L.F_RES | L.F_RELU2,
-                               wp2=ops.packed(lin.linear.weight), gn2=_gn(lin.norm), res=agts, eps=lin.norm.eps)
+            return ops.guarded(lambda: ops.agg_mlp(T, [ops.RelSpec(agts, ops.packed(self.agt.weight))],
+                                                   L.F_RELU1 | L.F_GEMM2 | L.F_GN2 | L.F_RES | L.F_RELU2,
+                                                   wp2=ops.packed(lin.linear.weight), gn2=_gn(lin.norm), res=agts,
+                                                   eps=lin.norm.eps))
         ps = pairs if pairs is not None else build_pairs(agt_idcs, agt_ctrs, ctx_idcs, ctx_ctrs, dist_th,
                                                          self.legacy_offsets)
         if (self.strict or train) and ps.count() == 0:
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
-        return self.run_train(agts, ctx, ps) if train else self.run(agts, ctx, ps)
+        return self.run_train(agts, ctx, ps) if train else ops.guarded(lambda: self.run(agts, ctx, ps))
 
     def run_train(self, agts: Tensor, ctx: Tensor, ps: ops.PairSet) -> Tensor:
         """Differentiable composition of the same arithmetic as run() (lanegcn.py:691-709): per-pair tensors are
@@ -440,7 +440,8 @@ class A2M(nn.Module):
             meta4 = torch.cat((graph["turn"], graph["control"].unsqueeze(1), graph["intersect"].unsqueeze(1)), 1)
             feat = A.gn_act(A.linear_gn(feat, w, col0=0) + F.linear(meta4, w[:, 128:132]), gn=self.meta.norm, relu=True)
         else:
-            feat = self.fuse_meta(feat, graph["turn"], graph["control"], graph["intersect"])
+            x_in = feat
+            feat = ops.guarded(lambda: self.fuse_meta(x_in, graph["turn"], graph["control"], graph["intersect"]))
         th = self.config["actor2map_dist"]
         ps = None
         if len(actors) > 0:
@@ -687,6 +688,12 @@ class Net(nn.Module):
         feats, rot, orig = eng.actor_inputs(scenes)
         sizes = [len(s["ctrs"]) for s in scenes]
         out = eng.forward(fb, feats, rot, orig, sizes, return_pairs=Att.strict)
+        if ops.get_guard() != "off" and ops.get_mma() == "f16x2" and int(out["nonfinite"].item()) != 0:
+            # an operand left fp16's range: the forward comes back with NaN rows; policy = re-run in bf16x3 or raise
+            if ops.get_guard() == "raise":
+                raise L.LgcnError("non-finite outputs in f16x2 mode: an operand left fp16's range (|x| >= 65504)")
+            with ops.mma_scope("bf16x3"):
+                out = eng.forward(fb, feats, rot, orig, sizes, return_pairs=Att.strict)
         if Att.strict and any(int(c) == 0 for c in torch.stack(out["n_pairs"]).flatten().tolist()):
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
         cls, reg, st = [], [], 0

@@ -51,6 +51,71 @@ class backward_mma:
         _mma = self.prev
 
 
+class mma_scope:
+    """``with ops.mma_scope("bf16x3"):`` -- matrix-core mode for the launches inside the block."""
+
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        global _mma
+        self.prev = _mma
+        _mma = L.MMA_NAMES[self.name]
+        return self
+
+    def __exit__(self, *a):
+        global _mma
+        _mma = self.prev
+
+
+# What happens when a forward in the range-restricted default mode (f16x2: operands below 65504) comes back with
+# non-finite features: "reroute" (default) runs it again in bf16x3 (fp32's exponent range, same fp32-grade
+# accuracy), "raise" raises LgcnError, "off" returns it as it is.
+_guard = os.environ.get("LGCN_GUARD", "reroute")
+
+
+def set_guard(policy: str):
+    global _guard
+    if policy not in ("reroute", "raise", "off"):
+        raise L.LgcnError("guard policy must be 'reroute', 'raise' or 'off'")
+    _guard = policy
+
+
+def get_guard() -> str:
+    return _guard
+
+
+def check_finite(flag: torch.Tensor, a: torch.Tensor, b: Optional[torch.Tensor] = None, bit: int = 1):
+    """flag[0] |= bit when a (or b) holds a NaN / inf (lgcn_check_finite); enqueued, no synchronisation."""
+    lib = L.load()
+    a = _dev(a, torch.float32, "a")
+    b = None if b is None else _dev(b, torch.float32, "b")
+    L.check(lib.lgcn_check_finite(_ptr(a), a.numel(), _ptr(b), 0 if b is None else b.numel(), _ptr(flag), bit, _stream()),
+            "lgcn_check_finite")
+
+
+def guarded(run, tensors_of=lambda out: (out,)):
+    """run() in the current matrix mode; in f16x2 the result's features are checked on the device (one 4-byte
+    device->host read) and a forward that overflowed fp16's range is run again in bf16x3 -- or raises, by policy.
+    Non-finite values that survive the re-run were in the inputs: returned as they are, like the reference does."""
+    out = run()
+    if _guard == "off" or _mma != L.MMA_F16X2:
+        return out
+    ts = [t for t in tensors_of(out) if t is not None and t.numel() > 0]
+    if not ts:
+        return out
+    flag = torch.zeros(1, dtype=torch.int32, device=ts[0].device)
+    for i in range(0, len(ts), 2):
+        check_finite(flag, ts[i], ts[i + 1] if i + 1 < len(ts) else None)
+    if int(flag.item()) == 0:
+        return out
+    if _guard == "raise":
+        raise L.LgcnError("non-finite features in f16x2 mode: an operand left fp16's range (|x| >= 65504); "
+                          "use ops.set_mma('bf16x3') or ops.set_guard('reroute')")
+    with mma_scope("bf16x3"):
+        return run()
+
+
 def _stream():
     # the raw hipStream_t of torch's current stream (torch.cuda.current_stream() costs ~9 us of Python per call)
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))

@@ -57,6 +57,17 @@ def _worker(rank, world, port, q):
         for i, p in enumerate(net.parameters()):
             want = sum(g[i] for g in every) / world
             assert torch.allclose(p.grad, want, atol=1e-6)
+        # ranks that disagree on WHICH parameters have a gradient (a relation without edges on one rank's batch,
+        # reference lanegcn.py:343-354): the bucket covers every parameter, zeros for the missing ones
+        two = torch.nn.ModuleList([torch.nn.Linear(4, 4, bias=False), torch.nn.Linear(4, 4, bias=False)])
+        for p_ in two.parameters():
+            torch.nn.init.constant_(p_, 0.5)
+        used = two[0] if rank == 0 else two[1]          # rank 0 only touches layer 0, rank 1 only layer 1
+        used(torch.ones(2, 4) * (rank + 1)).sum().backward()
+        assert (two[1].weight.grad is None) == (rank == 0)
+        D.allreduce_mean_grads(two.parameters())
+        assert torch.allclose(two[0].weight.grad, torch.full((4, 4), 2.0 * 1 / world))      # rank 0: sum over 2 rows of 1
+        assert torch.allclose(two[1].weight.grad, torch.full((4, 4), 2.0 * 2 / world))      # rank 1: 2 rows of 2
         D.barrier()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001

@@ -187,3 +187,51 @@ def test_bf16_mode_s2_vs_oracle(hip, ref_state_names, mma_mode):
         assert err <= 2e-2 * scale, (err, scale)
     finally:
         ops.set_mma(prev)
+
+
+def test_f16x2_overflow_is_seen_and_rerouted(hip, ref_state_names, mma_mode):
+    """Operands beyond fp16's 65504 in the default f16x2 mode: the forward comes back with NaN rows (never with
+    plausible numbers: every ReLU keeps a NaN), the device flag says so, and the guarded entry points re-run in
+    bf16x3 -- finite and equal to the oracle -- or raise, by policy."""
+    M, ops = hip
+    if mma_mode != "f16x2":
+        pytest.skip("f16x2 only")
+    from lanegcn_amd._lib import LgcnError
+    rng = np.random.default_rng(23)
+    n = 16 * 23 + 5
+    sd = O.seeded_state(ref_state_names, 11)
+    m2m = M.M2M(M.config)
+    m2m.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("m2m.")})
+    m2m = m2m.cuda().eval()
+    graph = multigraph(rng, n)
+    feat = torch.from_numpy(rng.normal(0, 1, (n, 128)).astype(np.float32)).relu()
+    feat[7, 3] = 1.0e5                 # one activation beyond fp16's range
+    feat[200, :] *= 3.0e4              # a row that sums past it in the gathers
+    want = O.m2m(feat, graph, sd)
+    assert torch.isfinite(want).all()
+    dgraph = {"pre": [{k: v.cuda() for k, v in e.items()} for e in graph["pre"]],
+              "suc": [{k: v.cuda() for k, v in e.items()} for e in graph["suc"]],
+              "left": {k: v.cuda() for k, v in graph["left"].items()},
+              "right": {k: v.cuda() for k, v in graph["right"].items()}, "feats": feat.cuda()}
+    scale = float(want.abs().max())
+    with torch.no_grad():
+        for impl in ("tiled", "fused"):
+            ops.set_laneconv_impl(impl)
+            try:
+                ops.set_guard("off")
+                raw = m2m(feat.cuda(), dict(dgraph))
+                assert not torch.isfinite(raw).all(), impl + ": the overflow must surface as NaN, not as numbers"
+                flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+                ops.check_finite(flag, raw)
+                assert int(flag.item()) == 1
+                ops.set_guard("raise")
+                with pytest.raises(LgcnError):
+                    m2m(feat.cuda(), dict(dgraph))
+                ops.set_guard("reroute")
+                got = m2m(feat.cuda(), dict(dgraph)).cpu()
+                assert torch.isfinite(got).all()
+                assert float((got - want).abs().max()) <= 1e-4 * max(1.0, scale), impl
+                assert ops.get_mma() == "f16x2"          # the mode is restored
+            finally:
+                ops.set_guard("reroute")
+                ops.set_laneconv_impl("tiled")

@@ -113,6 +113,68 @@ def test_bad_arguments_are_refused_without_launching(lib):
         assert l.lgcn_wgrad(C.byref(w), C.c_void_p(256), C.c_void_p(256), C.c_void_p(256), bad, None) == EINVAL
 
 
+def test_unknown_flag_bits_and_laneconv_arguments(lib):
+    """lgcn_agg_mlp refuses flag bits it does not know (the timing-only work-skipping bits exist in the
+    diagnostic build only); the LaneConv entry points validate geometry, groups and pointers before launching."""
+    l, mod = lib
+    EINVAL, ESHAPE, EALIGN = -1, -2, -3
+    p = mod.AggMlp()
+    p.n_rows, p.n_rel, p.out, p.mma = 10, 1, 256, 3
+    p.rel[0].src, p.rel[0].wp, p.rel[0].mode = 256, 256, mod.REL_IDENT
+    for bad in (1 << 8, 1 << 9, 1 << 6, 1 << 20):
+        p.flags = bad
+        assert l.lgcn_agg_mlp(C.byref(p), None) == EINVAL
+    m, c = C.c_int32(), C.c_int32()
+    assert l.lgcn_lc_config(mod.MMA_F32, 0, C.byref(m), C.byref(c)) == ESHAPE          # exact f32: lgcn_agg_mlp path
+    assert l.lgcn_lc_config(mod.MMA_F16X2, 2, C.byref(m), C.byref(c)) == EINVAL
+    geoms = {}
+    for mma in (mod.MMA_BF16X3, mod.MMA_F16X2, mod.MMA_BF16):
+        for v in (0, 1):
+            assert l.lgcn_lc_config(mma, v, C.byref(m), C.byref(c)) == 0
+            assert m.value % 16 == 0 and c.value >= m.value
+            geoms[(mma, v)] = (m.value, c.value)
+            assert l.lgcn_lc_plan_elems(1000, m.value, c.value) > 0
+            assert l.lgcn_lc_part_elems(1000, m.value, 1) == 0                           # one group: no partial sums
+            assert l.lgcn_lc_part_elems(1000, m.value, 4) == ((1000 + m.value - 1) // m.value) * 4 * m.value * 128
+    assert l.lgcn_lc_plan_elems(1000, 100, 200) == EINVAL                               # row block not supported
+    assert l.lgcn_lc_plan_elems(1000, 96, 64) == EINVAL                                 # cap < rows per block
+    M_, cap = geoms[(mod.MMA_F16X2, 0)]
+    gs = (C.c_int32 * 3)(0, 8, 15)
+    assert l.lgcn_lc_plan_build(None, None, 0, 14, M_, cap, 2, gs, None, None) == 0     # no nodes: nothing to do
+    assert l.lgcn_lc_plan_build(C.c_void_p(256), C.c_void_p(256), 100, 14, M_, cap, 2, gs, None, None) == EINVAL   # null plan
+    assert l.lgcn_lc_plan_build(C.c_void_p(256), C.c_void_p(256), 100, 14, M_, cap, 2, gs, C.c_void_p(260), None) == EALIGN
+    bad = (C.c_int32 * 3)(0, 8, 14)                                                     # groups must end at n_units
+    assert l.lgcn_lc_plan_build(C.c_void_p(256), C.c_void_p(256), 100, 14, M_, cap, 2, bad, C.c_void_p(256), None) == EINVAL
+    q = mod.LaneConv()
+    assert l.lgcn_laneconv_fwd(None, None) == EINVAL
+    q.mma = mod.MMA_F32
+    assert l.lgcn_laneconv_fwd(C.byref(q), None) == ESHAPE
+    q.mma, q.n_rows, q.rows_per_block, q.cap, q.n_units, q.n_groups = mod.MMA_F16X2, 100, M_, cap, 15, 1
+    q.gstart[0], q.gstart[1] = 0, 15
+    assert l.lgcn_laneconv_fwd(C.byref(q), None) == EINVAL                               # null pointers
+    q.rows_per_block = 80
+    assert l.lgcn_laneconv_fwd(C.byref(q), None) == EINVAL                               # not a geometry of this mode
+    q.rows_per_block, q.n_rows = M_, 0
+    assert l.lgcn_laneconv_fwd(C.byref(q), None) == 0                                    # no rows: no launch
+
+
+def test_shipped_library_reads_no_environment():
+    """The tuning knobs (LGCN_RB, LGCN_RING, ...) and the work-skipping flag bits are compiled into the diagnostic
+    builds only (make stamps / ablate): the product's kernel sources reach getenv only behind LGCN_TUNING."""
+    csrc = os.path.join(ROOT, "lanegcn-1_amd", "csrc")
+    for f in os.listdir(csrc):
+        if not f.endswith((".hip", ".hpp")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        for m in re.finditer(r"getenv", text):
+            head = text[:m.start()]
+            assert head.rfind("#ifdef LGCN_TUNING") > head.rfind("#endif"), f + ": getenv outside LGCN_TUNING"
+        assert "static int n = 0" not in text, f + ": function-local cache"
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    flags = [ln for ln in mk.splitlines() if ln.startswith("CXXFLAGS")][0]
+    assert "LGCN_TUNING" not in flags and "LGCN_ABLATE" not in flags and "LGCN_STAMPS" not in flags
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "lanegcn-1_amd")
     for dirpath, _, files in os.walk(pkg):

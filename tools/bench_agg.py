@@ -10,6 +10,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lanegcn_amd  # noqa: F401,E402
 from lanegcn_amd import _lib as L  # noqa: E402
+
+# the work-skipping flag bits (1 << 8: no in-loop gathers, 1 << 9: no MFMA passes) and the LGCN_RB* / LGCN_RING
+# environment knobs exist in the diagnostic library only (make -C lanegcn-1_amd/csrc ablate)
+_ABLATE = os.path.join(os.path.dirname(L.LIB_PATH), "liblgcn_ablate.so")
+if os.path.exists(_ABLATE):
+    L.LIB_PATH = _ABLATE
 from lanegcn_amd import data as gen  # noqa: E402
 from lanegcn_amd import lanegcn as M  # noqa: E402
 from lanegcn_amd import ops  # noqa: E402
