@@ -34,14 +34,15 @@ PEAK_NOTE = {"f32": "fp32-input MFMA (v_mfma_f32_32x32x2_f32), 157.3 TF dense",
 PEAK_HBM_GBPS = 8000.0             # HBM3E spec
 
 
-def measured_traffic(workload, mma):
-    """HBM bytes per LaneConv launch from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their
+def measured_traffic(workload, mma, impl="fused"):
+    """HBM bytes per LaneConv layer from the rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE in their
     own runs, gfx950 corrections of MI355X_MICROARCH.md applied) committed under profiles/; None when
-    no summary for this workload exists."""
+    no summary for this workload / implementation exists."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f).get("%s/%s" % (workload, mma), {}).get("laneconv_hbm_bytes_per_launch")
+            rec = json.load(f).get("%s/%s" % (workload, mma), {})
+        return rec.get("laneconv_hbm_bytes_per_launch" if impl == "fused" else "laneconv_tiled_hbm_bytes_per_layer")
     except (OSError, ValueError):
         return None
 
@@ -172,11 +173,12 @@ def stage_table(eng, fb, actors, reps=20):
     return out
 
 
-def laneconv_launch_us(eng, fb, feat_map, feat_m2m, reps=20):
-    """Average duration of one fused LaneConv launch without per-launch event overhead: the step's 8 LaneConv
-    launches (MapNet's 4 + M2M's 4, their own weights, the batch's CSR plan) captured back-to-back in one
-    hipGraph and replayed `reps` times between ONE HIP event pair on the launch stream.  This is the figure the
-    rocprofv3 kernel trace reports (profiles/); the per-launch event pairs of `kernel_avg_us` add ~5 us each."""
+def laneconv_launch_us(eng, fb, feat_map, feat_m2m, impl, reps=20):
+    """Average duration of one LaneConv LAYER without per-launch event overhead: the step's 8 layers (MapNet's 4 +
+    M2M's 4, their own weights, the batch's CSR plan) captured back-to-back in one hipGraph and replayed `reps` times
+    between ONE HIP event pair on the launch stream.  impl "fused": one k_agg_mlp launch per layer; "tiled": the
+    weight-stationary k_lc_tile (+ k_lc_combine when the plan has several unit groups).  The rocprofv3 kernel trace
+    (profiles/) reports the same figures; the per-launch event pairs of `kernel_avg_us` add ~5 us each."""
     import torch
     from lanegcn_amd import lanegcn as M
     from lanegcn_amd import ops
@@ -185,8 +187,8 @@ def laneconv_launch_us(eng, fb, feat_map, feat_m2m, reps=20):
                          fb.n_nodes)
 
     def body():
-        M.lane_conv(eng.map_net.fuse, feat_map, plan, fb.num_scales)
-        M.lane_conv(eng.m2m.fuse, feat_m2m, plan, fb.num_scales)
+        M.lane_conv(eng.map_net.fuse, feat_map, plan, fb.num_scales, impl=impl)
+        M.lane_conv(eng.m2m.fuse, feat_m2m, plan, fb.num_scales, impl=impl)
 
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -207,6 +209,146 @@ def laneconv_launch_us(eng, fb, feat_map, feat_m2m, reps=20):
     return e0.elapsed_time(e1) * 1e3 / (8 * reps)
 
 
+def roofline_of(layer_us, n_nodes, sum_e, mma, workload, impl, launches):
+    """`roofline` object of one LaneConv implementation: achieved = ALGORITHMIC bytes / flops of one layer
+     / the layer's measured duration.  The binding roof is the one the algorithmic work takes longer on
+    in this arithmetic mode (fp32 MFMA-bound on paper; the 16-bit-plane modes, >= 417 TF effective, HBM-bound on
+    paper: 69 MB / 8 TB/s = 8.6 us vs 4.3 GFLOP / 833 TF = 5.2 us); both fractions are reported."""
+    flops, byts = laneconv_algorithmic(n_nodes, sum_e)
+    lc_s = layer_us * 1e-6
+    ach, ach_gbs = flops / lc_s / 1e12, byts / lc_s / 1e9
+    t_hbm, t_mfma = byts / (PEAK_HBM_GBPS * 1e9), flops / (PEAK_TFLOPS[mma] * 1e12)
+    hbm = t_hbm >= t_mfma
+    return {
+        "bound": "hbm" if hbm else "mfma",
+        "achieved": ach_gbs if hbm else ach, "peak": PEAK_HBM_GBPS if hbm else PEAK_TFLOPS[mma],
+        "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach_gbs / PEAK_HBM_GBPS if hbm else ach / PEAK_TFLOPS[mma],
+        "traffic": measured_traffic(workload, mma, impl),
+        "hbm": {"achieved_GBps": ach_gbs, "peak_GBps": PEAK_HBM_GBPS, "frac": ach_gbs / PEAK_HBM_GBPS, "roof_us": t_hbm * 1e6},
+        "mfma": {"achieved_TFLOPs": ach, "peak_TFLOPs": PEAK_TFLOPS[mma], "frac": ach / PEAK_TFLOPS[mma],
+                 "roof_us": t_mfma * 1e6, "peak_note": PEAK_NOTE[mma], "frac_of_f32_mfma_peak": ach / PEAK_TFLOPS["f32"]},
+        "kernel": impl, "launches_per_layer": launches, "avg_launch_us": layer_us,
+        "timing": "the step's 8 LaneConv layers captured back-to-back, replayed 20x between one HIP event pair on the "
+                  "launch stream; avg_launch_us = per LAYER (all of the layer's launches)",
+        "algorithmic_flops_per_launch": flops, "algorithmic_bytes_per_launch": byts,
+    }
+
+
+def time_steps(step, steps, warmup, barrier, dev):
+    from lanegcn_amd import dist as D
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    return D.max_over_ranks(time.perf_counter() - t0, dev)     # slowest rank
+
+
+def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup):
+    """One arithmetic mode: S forwards in flight (the headline figure) and one forward at a time, both captured in
+    hipGraphs.  Several forwards in flight run LaneConv as ONE elastic launch per layer ("fused": it spreads over
+    whatever CUs the other streams leave free); a single forward runs the weight-stationary pair ("tiled": fewer
+    bytes per row through a CU, the faster one when it has the chip to itself).  DESIGN.md section 4."""
+    from lanegcn_amd import data as gen
+    from lanegcn_amd import dist as D
+    from lanegcn_amd import ops
+    from lanegcn_amd.engine import HotPathEngine, collate_flat
+    ops.set_mma(mma)
+    S = max(1, args.streams)
+    impl_multi = args.laneconv or ("fused" if S > 1 or mma in ("f32", "bf16x3") else "tiled")
+    impl_one = args.laneconv or ("fused" if mma in ("f32", "bf16x3") else "tiled")
+    eng_multi = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"], lane_impl=impl_multi)
+    eng_one = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"], lane_impl=impl_one)
+    res = {"laneconv_impl": {"in_flight": impl_multi, "single": impl_one}}
+    if args.no_graph:
+        step = lambda: eng_one.forward(fb, actors, mapnet_only=args.mapnet_only)
+        elapsed = time_steps(step, steps, warmup, D.barrier, dev)
+        res.update(ms_per_step=elapsed / steps * 1e3, elapsed=elapsed, streams=1)
+        res["laneconv_impl"]["in_flight"] = impl_one
+        return res, eng_one
+    # the lane streams are created FIRST: torch hands out its pool streams in order and ROCm maps consecutive HIP
+    # streams to consecutive hardware queues (4 by default), so these S streams get S distinct queues
+    lane_streams = [torch.cuda.Stream() for _ in range(S)]
+    lanes = []
+    for j in range(S):
+        sc = scenes if j == 0 else gen.synth_batch(args.workload, seed=100 + rank + 1000 * j, n_scenes=args.scenes)
+        fbj = fb if j == 0 else collate_flat(sc, dev)
+        aj = actors if j == 0 else torch.randn(fbj.n_actors, C, device=dev).relu()
+        gj, oj = eng_multi.capture(fbj, aj, mapnet_only=args.mapnet_only)
+        lanes.append((lane_streams[j], gj, oj, fbj, aj))
+    counter = [0]
+
+    def step():
+        # S independent batches, one captured forward each, replayed round-robin on S streams: step k runs on stream
+        # k % S, so up to S forwards overlap on the GPU (every step is still a full batch-32 pass)
+        st, gj = lanes[counter[0] % len(lanes)][:2]
+        counter[0] += 1
+        with torch.cuda.stream(st):
+            gj.replay()
+
+    elapsed = time_steps(step, steps, warmup, D.barrier, dev)
+    res.update(ms_per_step=elapsed / steps * 1e3, elapsed=elapsed, streams=S)
+    # the range guard's device flag is part of every captured forward: none of them may have tripped
+    assert not any(int(l[2]["nonfinite"].item()) for l in lanes if "nonfinite" in l[2]), "non-finite features in mode %s" % mma
+    if impl_one == impl_multi:
+        g1, o1 = lanes[0][1], lanes[0][2]
+    else:
+        g1, o1 = eng_one.capture(fb, actors, mapnet_only=args.mapnet_only)
+    single = time_steps(g1.replay, steps, warmup, D.barrier, dev)
+    assert "nonfinite" not in o1 or int(o1["nonfinite"].item()) == 0
+    res["single_ms_per_step"] = single / steps * 1e3
+    return res, eng_one
+
+
+def extra_timings(mods, scenes, dev):
+    """The reference-facing calls on the same batch (not part of `value`): the drop-in ``Net.forward(data)`` under
+    no_grad (host collate of the dict-of-lists batch included) and one training step (forward + loss + backward +
+    Adam, reference train.py:179-190)."""
+    from lanegcn_amd import data as gen
+    from lanegcn_amd import lanegcn as M
+    out = {}
+    try:
+        torch.manual_seed(4321)
+        net = M.Net(M.config).to(dev)
+        for name in ("map_net", "a2m", "m2m", "m2a", "a2a"):
+            getattr(net, name).load_state_dict(mods[name].state_dict())
+        batch = gen.collate_fn([gen.from_numpy(s) for s in scenes])
+        net.eval()
+        with torch.no_grad():
+            for _ in range(3):
+                net(batch)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(8):
+                t0 = time.perf_counter()
+                net(batch)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+        out["net_forward_dropin_ms"] = float(np.median(ts)) * 1e3
+        net.train()
+        loss_fn = M.Loss(M.config).to(dev)
+        from lanegcn_amd.utils import Optimizer
+        opt = Optimizer(net.parameters(), M.config)
+        ts = []
+        for i in range(5):
+            t0 = time.perf_counter()
+            loss = loss_fn(net(batch), batch)["loss"]
+            opt.zero_grad()
+            loss.backward()
+            opt.step(0.0)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        out["train_step_ms"] = float(np.median(ts[1:])) * 1e3
+    except Exception as e:      # noqa: BLE001 -- auxiliary figures must not take the headline down with them
+        out["extra_timings_error"] = repr(e)[:300]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -222,6 +364,11 @@ def main():
                     help="forward graphs kept in flight on separate HIP streams (each on its own batch)")
     ap.add_argument("--mma", default=None, choices=["f32", "bf16x3", "f16x2", "bf16"],
                     help="matrix-core mode (default: LGCN_MMA or f16x2 = fp32-grade 2-way fp16 split)")
+    ap.add_argument("--laneconv", default=None, choices=["fused", "tiled"],
+                    help="force one LaneConv implementation (default: fused with several forwards in flight, tiled for one)")
+    ap.add_argument("--other-modes", default="f32,bf16x3",
+                    help="arithmetic modes reported next to the headline one in `modes` (comma list, '' = none)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the drop-in Net.forward / training-step timings")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -241,7 +388,7 @@ def main():
     if world > 1:
         import torch.distributed as tdist
         tdist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
-    from lanegcn_amd.engine import HotPathEngine, collate_flat
+    from lanegcn_amd.engine import collate_flat
 
     if args.mma:
         ops.set_mma(args.mma)
@@ -252,130 +399,65 @@ def main():
     actors_cpu = torch.from_numpy(
         np.random.default_rng(7 + rank).normal(0, 1, (fb.n_actors, C)).astype(np.float32)).relu()
     actors = actors_cpu.to(dev)
-    eng = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"])
-
     log("rank %d: batch ready (N=%d nodes, A=%d actors, sumE=%d)" % (rank, fb.n_nodes, fb.n_actors, sum(fb.n_edges)))
-    if args.no_graph:
-        step = lambda: eng.forward(fb, actors, mapnet_only=args.mapnet_only)
-        for _ in range(3):
-            step()
-    elif args.streams <= 1:
-        graph, _ = eng.capture(fb, actors, mapnet_only=args.mapnet_only)
-        step = graph.replay
-    else:
-        # S independent batches, one captured forward each, replayed round-robin on S streams: step k runs
-        # on stream k % S, so up to S forwards overlap on the GPU (every step is still a full batch-32 pass)
-        # the lane streams are created FIRST: torch hands out its pool streams in order and ROCm maps consecutive
-        # HIP streams to consecutive hardware queues (4 by default), so these S streams get S distinct queues;
-        # created between the captures (each capture takes a side stream from the same pool) lanes 0 / 2 and
-        # 1 / 3 shared a queue and only two forwards ever overlapped
-        lane_streams = [torch.cuda.Stream() for _ in range(args.streams)]
-        lanes = []
-        for j in range(args.streams):
-            sc = scenes if j == 0 else gen.synth_batch(args.workload, seed=100 + rank + 1000 * j, n_scenes=args.scenes)
-            fbj = fb if j == 0 else collate_flat(sc, dev)
-            aj = actors if j == 0 else torch.randn(fbj.n_actors, C, device=dev).relu()
-            gj, _ = eng.capture(fbj, aj, mapnet_only=args.mapnet_only)
-            lanes.append((lane_streams[j], gj))
-        counter = [0]
 
-        def step():
-            st, gj = lanes[counter[0] % len(lanes)]
-            counter[0] += 1
-            with torch.cuda.stream(st):
-                gj.replay()
+    head, eng = run_mode(args, mma, mods, scenes, fb, actors, dev, rank, args.steps, args.warmup)
+    elapsed = head["elapsed"]
+    log("rank %d: %d steps in %.4f s (%s)" % (rank, args.steps, elapsed, mma))
 
-    barrier = D.barrier
-
-    log("rank %d: forward %s" % (rank, "eager" if args.no_graph else "captured in a hipGraph"))
-    if os.environ.get("LGCN_BENCH_PREWARM") and not args.no_graph and args.streams > 1:
-        for n in range(1, len(lanes) + 1):
-            for r in range(60):
-                st_, g_ = lanes[r % n]
-                with torch.cuda.stream(st_):
-                    g_.replay()
-            torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev)     # slowest rank
-
-    log("rank %d: %d steps in %.4f s" % (rank, args.steps, elapsed))
-    single = None
-    if not args.no_graph and args.streams > 1:       # same steps, one forward at a time (latency view)
-        g1 = lanes[0][1]
-        for _ in range(args.warmup):
-            g1.replay()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            g1.replay()
-        torch.cuda.synchronize()
-        single = D.max_over_ranks(time.perf_counter() - t1, dev)
-    # per-kernel durations (HIP events on the launch stream), eager launches of the same forward
+    # per-kernel durations (HIP events on the launch stream), eager launches of the single-forward engine
     with ops.kernel_timer() as kt:
         for _ in range(10):
             eng.forward(fb, actors, mapnet_only=args.mapnet_only)
     ksum = kt.summary()
-    lc_graph_us = None
-    stages_tab = None
+    lc_us, stages_tab, modes, extras = {}, None, {}, {}
+    n_scenes = len(scenes)
     if rank == 0:
         st = eng.forward(fb, actors, stages=not args.mapnet_only, mapnet_only=args.mapnet_only)
         torch.cuda.synchronize()
-        assert all(torch.isfinite(v).all() for v in st.values() if torch.is_tensor(v))
-        lc_graph_us = laneconv_launch_us(eng, fb, st["nodes"] if args.mapnet_only else st["map_net"],
-                                         st["nodes"] if args.mapnet_only else st["a2m"])
+        assert all(torch.isfinite(v).all() for v in st.values() if torch.is_tensor(v) and v.is_floating_point())
+        f_map = st["nodes"] if args.mapnet_only else st["map_net"]
+        f_m2m = st["nodes"] if args.mapnet_only else st["a2m"]
+        for impl in (("fused",) if mma == "f32" else ("fused", "tiled")):
+            lc_us[impl] = laneconv_launch_us(eng, fb, f_map, f_m2m, impl)
         stages_tab = None if args.mapnet_only or world > 1 else stage_table(eng, fb, actors)
+    if world == 1 and not args.mapnet_only and not args.no_graph:
+        for m in [v for v in args.other_modes.split(",") if v and v != mma]:
+            r, e_m = run_mode(args, m, mods, scenes, fb, actors, dev, rank, max(40, args.steps // 2), args.warmup)
+            stm = e_m.forward(fb, actors, stages=True)
+            lcm = {impl: laneconv_launch_us(e_m, fb, stm["map_net"], stm["a2m"], impl)
+                   for impl in (("fused",) if m == "f32" else ("fused", "tiled"))}
+            dom = r["laneconv_impl"]["in_flight"]
+            modes[m] = {
+                "value": n_scenes / (r["ms_per_step"] * 1e-3), "unit": "scenes/s", "ms_per_step": r["ms_per_step"],
+                "streams": r["streams"], "single_stream_value": n_scenes / (r["single_ms_per_step"] * 1e-3),
+                "single_stream_ms_per_step": r["single_ms_per_step"], "laneconv_impl": r["laneconv_impl"],
+                "laneconv_layer_us": lcm,
+                "roofline": {k: roofline_of(lcm[dom], fb.n_nodes, sum(fb.n_edges), m, args.workload, dom, 1)[k]
+                             for k in ("bound", "achieved", "peak", "unit", "frac", "hbm", "mfma")},
+            }
+            log("mode %s: %.0f scenes/s" % (m, modes[m]["value"]))
+        ops.set_mma(mma)
+        if not args.no_extras:
+            extras = extra_timings(mods, scenes, dev)
 
     if rank == 0:
-        n_scenes = len(scenes)
         sum_e = sum(fb.n_edges)
-        lc_ms = lc_graph_us * 1e-3
-        flops, byts = laneconv_algorithmic(fb.n_nodes, sum_e)
-        ach = flops / (lc_ms * 1e-3) / 1e12
         how = "eager" if args.no_graph else "hipGraph replay" + (
-            "" if args.streams <= 1 else ", %d forwards in flight on %d streams" % (args.streams, args.streams))
+            "" if head["streams"] <= 1 else ", %d forwards in flight on %d streams" % (head["streams"], head["streams"]))
         what = ("MapNet only (graph_gather+CSR plan+stem+4 LaneConv)" if args.mapnet_only
                 else "hot path forward (graph_gather+CSR plan+MapNet+A2M+M2M+M2A+A2A)")
         workload_desc = ("%s: %s, %d scenes/GPU, %d lane nodes, %d edges, %d actors, random-init weights, inputs "
                          "resident in HBM, %s" % (args.workload, what, n_scenes, fb.n_nodes, sum_e, fb.n_actors, how))
-        # The binding roof of the dominant kernel in this arithmetic mode: the one its algorithmic work takes
-        # longer on (fp32 MFMA-bound on paper; the 16-bit-plane modes with >= 833 TF effective peak
-        # are HBM-bound on paper: 69 MB / 8 TB/s = 8.6 us vs 4.3 GFLOP / 833 TF = 5.2 us).  Both fractions reported.
-        lc_s = lc_ms * 1e-3
-        t_hbm, t_mfma = byts / (PEAK_HBM_GBPS * 1e9), flops / (PEAK_TFLOPS[mma] * 1e12)
-        ach_gbs = byts / lc_s / 1e9
-        roofline = {
-            "bound": "hbm" if t_hbm >= t_mfma else "mfma",
-            "achieved": ach_gbs if t_hbm >= t_mfma else ach,
-            "peak": PEAK_HBM_GBPS if t_hbm >= t_mfma else PEAK_TFLOPS[mma],
-            "unit": "GB/s" if t_hbm >= t_mfma else "TFLOP/s",
-            "frac": ach_gbs / PEAK_HBM_GBPS if t_hbm >= t_mfma else ach / PEAK_TFLOPS[mma],
-            "traffic": measured_traffic(args.workload, mma),
-            "hbm": {"achieved_GBps": ach_gbs, "peak_GBps": PEAK_HBM_GBPS, "frac": ach_gbs / PEAK_HBM_GBPS,
-                    "roof_us": t_hbm * 1e6},
-            "mfma": {"achieved_TFLOPs": ach, "peak_TFLOPs": PEAK_TFLOPS[mma], "frac": ach / PEAK_TFLOPS[mma],
-                     "roof_us": t_mfma * 1e6, "peak_note": PEAK_NOTE[mma],
-                     "frac_of_f32_mfma_peak": ach / PEAK_TFLOPS["f32"]},
-            "kernel": ("lgcn::k_agg_mlp<1>" if mma == "f32" else "lgcn::k_agg_mlp_bf<RB,NP,1>")
-                      + " (fused LaneConv layer, 8 launches/step)",
-            "avg_launch_us": lc_ms * 1e3,
-            "avg_launch_us_eager_event_pairs": float(np.mean(ksum["laneconv"])) * 1e3,
-            "timing": "8 LaneConv launches of the step captured back-to-back, replayed 20x between one HIP "
-                      "event pair on the launch stream",
-            "algorithmic_flops_per_launch": flops,
-            "algorithmic_bytes_per_launch": byts,
-            "note": "traffic = HBM bytes per launch from the PMC passes (profiles/pmc_traffic.json); it is below the "
-                    "algorithmic bytes because the 15 gathers of a row hit L2; the measured limiter is the L2 -> CU "
-                    "weight stream (DESIGN.md section 4)",
-        }
+        names = {"fused": ("lgcn::k_agg_mlp<1>" if mma == "f32" else "lgcn::k_agg_mlp_bf<RB,F,1>") + " (one-launch LaneConv layer)",
+                 "tiled": "lgcn::k_lc_tile<F,V> + lgcn::k_lc_combine<F> (weight-stationary LaneConv layer)"}
+        dom = head["laneconv_impl"]["in_flight"]
+        roofline = roofline_of(lc_us[dom], fb.n_nodes, sum_e, mma, args.workload, dom, 1 if dom == "fused" else 2)
+        roofline["kernel"] = names[dom] + ", 8 layers/step: the LaneConv of the timed configuration"
+        roofline["avg_launch_us_eager_event_pairs"] = float(np.mean(ksum["laneconv"])) * 1e3
+        roofline["note"] = ("traffic = HBM bytes per layer from the PMC passes (profiles/pmc_traffic.json); it is below the "
+                            "algorithmic bytes because the gathers of a row hit L2; what binds the one-launch kernel is the "
+                            "L2 -> CU weight stream, what binds the weight-stationary one is MFMA issue (DESIGN.md section 4)")
         line = {
             "metric": "Argoverse scenes/sec forward (batch=32, ~10k lane nodes)",
             "value": args.gpus * n_scenes * args.steps / elapsed,
@@ -383,23 +465,33 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16" if mma == "bf16" else "f32", "mma": mma, "data": "synthetic",
+            "dtype": {"f32": "f32", "bf16x3": "f32 (3 bf16 planes per operand, 6 products, fp32 accumulate)",
+                      "f16x2": "f32 (2 fp16 planes per operand, 3 products, fp32 accumulate; range-guarded)",
+                      "bf16": "bf16"}[mma],
+            "mma": mma, "data": "synthetic",
             "config": {"workload": workload_desc,
                        "scenes_per_gpu": n_scenes, "parallelism": "dp%d (independent scene shards)" % args.gpus},
             "roofline": roofline,
+            "laneconv": {"impl": head["laneconv_impl"], "layer_us": lc_us,
+                         "roofline_by_impl": {k: {kk: roofline_of(v, fb.n_nodes, sum_e, mma, args.workload, k, 1)[kk]
+                                                  for kk in ("bound", "achieved", "peak", "unit", "frac")}
+                                              for k, v in lc_us.items()}},
             "kernel_avg_us": {k: float(np.mean(v)) * 1e3 for k, v in ksum.items()},
-            "streams": 1 if args.no_graph else args.streams,
+            "streams": head["streams"],
         }
         if stages_tab is not None:
             line["stages"] = stages_tab
-        if single is not None:
-            line["single_stream"] = {"value": args.gpus * n_scenes * args.steps / single, "unit": "scenes/s",
-                                     "ms_per_step": single / args.steps * 1e3}
+        if "single_ms_per_step" in head:
+            line["single_stream"] = {"value": args.gpus * n_scenes / (head["single_ms_per_step"] * 1e-3), "unit": "scenes/s",
+                                     "ms_per_step": head["single_ms_per_step"], "laneconv_impl": head["laneconv_impl"]["single"]}
+        if modes:
+            line["modes"] = modes
+        line.update(extras)
         if args.cpu_seconds > 0 and world == 1:      # reported baseline: rank 0, N = 1 only
             line["cpu_baseline"] = cpu_baseline(scenes, actors_cpu, mods, args.cpu_seconds)
             line["speedup_vs_cpu_all_cores"] = line["value"] / args.gpus / line["cpu_baseline"]["value"]
         print(json.dumps(line), flush=True)
-    barrier()
+    D.barrier()
     if world > 1:
         tdist.destroy_process_group()
 

@@ -230,7 +230,8 @@ def lane_conv(fuse: nn.ModuleDict, feat: Tensor, plan: ops.LanePlan, num_scales:
     over LDS-resident source rows + a combine launch; "fused": one lgcn_agg_mlp launch per layer (the only
     implementation of the exact-f32 mode, and the one the autograd path records)."""
     keys = rel_keys(num_scales)
-    impl = impl or ops.laneconv_impl()
+    if impl is None:      # three-plane operands leave the tiled kernel too little LDS per row block to pay (measured)
+        impl = "fused" if ops.get_mma() == "bf16x3" else ops.laneconv_impl()
     lcp = ops.lc_plan(plan) if impl == "tiled" and tile_rb == 0 and plan.n_nodes > 0 else None
     if lcp is not None:
         part = ops.lc_part(lcp)

@@ -38,6 +38,11 @@ def test_bench_default_line():
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     cpu = out["cpu_baseline"]
     assert cpu["kind"] in ("port", "reference") and cpu["value"] > 0 and cpu["cores"] >= 1 and cpu["sample"]
+    # the strict-f32 and the range-safe split mode ride in the same line, and so do the reference-facing calls
+    for m in ("f32", "bf16x3"):
+        assert out["modes"][m]["value"] > 0 and out["modes"][m]["roofline"]["frac"] > 0 and out["modes"][m]["laneconv_layer_us"]
+    assert out["net_forward_dropin_ms"] > 0 and out["train_step_ms"] > 0, out.get("extra_timings_error")
+    assert set(out["laneconv"]["layer_us"]) == {"fused", "tiled"}
 
 
 def test_bench_single_stream_eager_mapnet():
