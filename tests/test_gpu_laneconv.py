@@ -165,6 +165,56 @@ def test_mapnet_s1_vs_oracle(hip, ref_state_names):
     assert torch.equal(got, got2), "not bitwise repeatable"
 
 
+def test_mapnet_s1_exact_f32_mode_vs_oracle(hip, ref_state_names, mma_mode):
+    """BASELINE config 2 as stated: MapNet LaneConv only, 10k nodes / 60k edges, fp32 (the exact-f32 MFMA mode)."""
+    M, ops = hip
+    if mma_mode != "f16x2":
+        pytest.skip("runs once")
+    from lanegcn_amd import data as gen
+    prev = ops.get_mma()
+    ops.set_mma("f32")
+    try:
+        sd = O.seeded_state(ref_state_names, 7)
+        mn = M.MapNet(M.config)
+        mn.load_state_dict({k[8:]: v for k, v in sd.items() if k.startswith("map_net.")})
+        mn = mn.cuda().eval()
+        scenes = [to_torch_scene(s) for s in gen.synth_batch("S1", seed=2)]
+        with torch.no_grad():
+            got, _, _ = mn(M.graph_gather([s["graph"] for s in scenes]))
+        want = O.mapnet(O.graph_gather([s["graph"] for s in scenes]), sd)
+        assert got.shape == (10008, 128)
+        assert float((got.cpu() - want).abs().max()) <= FTOL
+    finally:
+        ops.set_mma(prev)
+
+
+def test_bf16_hot_path_s2_vs_oracle(hip, ref_state_names, mma_mode):
+    """BASELINE config 3: the full FusionNet path (MapNet + A2M + M2M + M2A + A2A), batch 32 (S2), single bf16
+    product.  No reference counterpart exists for bf16; bar = 2e-2 of each stage's feature scale vs the fp32 oracle
+    (hard part 6); index work is the same bit-exact kernels as in every mode."""
+    M, ops = hip
+    if mma_mode != "f16x2":
+        pytest.skip("runs once")
+    from lanegcn_amd import data as gen
+    from test_gpu_parity import make_modules, run_hot_path
+    prev = ops.get_mma()
+    ops.set_mma("bf16")
+    try:
+        sd = O.seeded_state(ref_state_names, 3)
+        mods = make_modules(M, sd)
+        scenes = [to_torch_scene(s) for s in gen.synth_batch("S2", seed=1)]
+        A = sum(len(s["ctrs"]) for s in scenes)
+        actors = torch.from_numpy(np.random.default_rng(2).normal(0, 1, (A, 128)).astype(np.float32)).relu()
+        out, _ = run_hot_path(M, mods, scenes, actors)
+        want = O.hot_path(O.graph_gather([s["graph"] for s in scenes]), actors, [s["ctrs"] for s in scenes], sd)
+        for k in ("map_net", "a2m", "m2m", "m2a", "a2a"):
+            w = want[k].numpy()
+            err, scale = float(np.abs(out[k] - w).max()), float(np.abs(w).max())
+            assert err <= 2e-2 * scale, (k, err, scale)
+    finally:
+        ops.set_mma(prev)
+
+
 def test_bf16_mode_s2_vs_oracle(hip, ref_state_names, mma_mode):
     """BASELINE config 3 (bf16): one bf16 product, S2 batch; bar 2e-2 relative to the feature scale."""
     M, ops = hip

@@ -74,7 +74,16 @@ def test_training_step_matches_reference(golden, train_golden, ref_state_names, 
         if key.startswith("grad/"):
             n = key[5:]
             worst[n] = rel_err(params[n].grad.cpu().numpy(), ref)
-    bar = 5e-3 if mma == "f32" else 1e-4
+    # The looser bar is only granted when the forward really has a ReLU input on the knife edge: count the sign
+    # flips of the A2M.meta output (62,208 ReLU inputs) between this build and the oracle, and check that every
+    # flipped entry is one whose value is ~0 on both sides.
+    flips = meta_relu_flips(net, scenes, ref_state_names, int(train_golden["seed"]))
+    if mma == "f32":
+        assert 0 < len(flips) <= 2, flips
+    else:
+        assert len(flips) == 0, flips
+    assert all(max(abs(a), abs(b)) <= 1e-5 for a, b in flips), flips
+    bar = 5e-3 if flips else 1e-4
     assert max(worst.values()) <= bar, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
 
     # Adam step through the Optimizer wrapper (utils.py:98-162): lr schedule + update
@@ -87,6 +96,70 @@ def test_training_step_matches_reference(golden, train_golden, ref_state_names, 
             # Adam's first step is lr * g / (|g| + 1e-8): entries whose gradient is ~1e-8 amplify the f32-mode
             # mask flip above into a full +-lr move, so there a handful of entries may differ
             assert close.all() if mma != "f32" else close.mean() >= 0.995, (key, float(close.mean()))
+
+
+def meta_relu_flips(net, scenes, ref_state_names, seed):
+    """(value here, value in the oracle) of every A2M.meta output entry (lanegcn.py:387-395) that is zero on one
+    side and positive on the other."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import lanegcn as M
+    sd = O.seeded_state(ref_state_names, seed)
+    tscenes = [{k: v for k, v in s.items()} for s in scenes]
+    from conftest import to_torch_scene
+    tscenes = [to_torch_scene(s) for s in scenes]
+    g_ref = O.graph_gather([s["graph"] for s in tscenes])
+    nodes_ref = O.mapnet(g_ref, sd)
+    meta_in = torch.cat((nodes_ref, g_ref["turn"], g_ref["control"].unsqueeze(1), g_ref["intersect"].unsqueeze(1)), 1)
+    want = O.linear_block(meta_in, sd, "a2m.meta")
+    with torch.no_grad():
+        graph = M.graph_gather([s["graph"] for s in tscenes])
+        was = net.training
+        net.eval()
+        nodes, _, _ = net.map_net(graph)
+        got = net.a2m.fuse_meta(nodes, graph["turn"], graph["control"], graph["intersect"]).cpu()
+        net.train(was)
+    idx = torch.nonzero((got > 0) != (want > 0))
+    return [(float(got[i, j]), float(want[i, j])) for i, j in idx.tolist()]
+
+
+def test_training_step_batch32_matches_reference(ref_state_names):
+    """BASELINE config 4: the training step at batch 32 (workload S2, 10,368 nodes / 1,600 actors) against the
+    reference's own loss and gradients (tests/golden/train_b32.npz, make_golden.py): loss scalars, every
+    parameter's gradient norm, and the hot-path gradients of the fixture element-wise (matrices: every 8th row)."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import data as gen
+    from lanegcn_amd import lanegcn as M
+    with np.load(os.path.join(GOLDEN_DIR, "train_b32.npz")) as z:
+        tg = {k: z[k] for k in z.files}
+    scenes = gen.synth_batch("S2", seed=int(tg["batch_seed"]))
+    assert len(scenes) == 32
+    net = M.Net(M.config)
+    net.load_state_dict(O.seeded_state(ref_state_names, int(tg["seed"])), strict=True)
+    net = net.cuda().train()
+    batch = gen.collate_fn([gen.from_numpy(s) for s in scenes])
+    loss_out = M.Loss(M.config).cuda()(net(batch), batch)
+    loss_out["loss"].backward()
+    torch.cuda.synchronize()
+    assert loss_out["num_cls"] == int(tg["loss/num_cls"]) and loss_out["num_reg"] == int(tg["loss/num_reg"])
+    for k in ("cls_loss", "reg_loss", "loss"):
+        assert float(loss_out[k].detach()) == pytest.approx(float(tg["loss/" + k]), rel=5e-5), k
+    names = json.load(open(os.path.join(GOLDEN_DIR, "param_names.json")))
+    params = dict(net.named_parameters())
+    norms = np.array([float(params[n].grad.norm()) if params[n].grad is not None else -1.0 for n in names])
+    ref_norms = tg["grad_norms"]
+    bad = [(n, a, b) for n, a, b in zip(names, norms, ref_norms) if abs(a - b) > 3e-3 * b + 1e-6]
+    assert not bad, bad[:5]
+    worst = {}
+    for key, ref in tg.items():
+        if key.startswith("grad/"):
+            g = params[key[5:]].grad.cpu().numpy()
+            g = g[::8] if g.shape != ref.shape else g
+            assert g.shape == ref.shape, key
+            worst[key[5:]] = rel_err(g, ref)
+    # 1.3 M ReLU inputs per layer at this size: a few land on the other side of zero under any change of summation
+    # order, each moves a handful of upstream entries by ~1e-3 of the tensor's scale (see the batch-4 test)
+    assert max(worst.values()) <= 5e-3, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    assert np.median(list(worst.values())) <= 2e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
 
 
 def test_training_forward_equals_inference_forward(golden, ref_state_names, mma):

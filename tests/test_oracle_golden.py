@@ -98,3 +98,31 @@ def test_dilated_nbrs_edge_sets():
     ref = O.dilated_nbrs({"u": u, "v": v}, n, 6)
     for a, b in zip(mine, ref):
         assert set(zip(a["u"].tolist(), a["v"].tolist())) == set(zip(b["u"].tolist(), b["v"].tolist()))
+
+
+def test_dilated_nbrs_vs_the_reference_itself(golden):
+    """a14 pinned to the reference: scales 1..5 that the reference's own data.dilated_nbrs (data.py:520-534, scipy
+    csr products) produced for the scale-0 pre / suc lists of the fixture scenes (tests/golden/make_golden.py), as
+    sorted edge sets, against the product's scipy-free version and the oracle's restatement."""
+    from golden_io import load_scenes
+    from lanegcn_amd import data as gen
+    scenes = load_scenes(golden)
+    seen = 0
+    for i, sc in enumerate(scenes):
+        n = int(sc["graph"]["num_nodes"])
+        for k1 in ("pre", "suc"):
+            e0 = {k: np.asarray(v, np.int64) for k, v in sc["graph"][k1][0].items()}
+            mine, orc = gen.dilated_nbrs(e0, n, 6), O.dilated_nbrs(e0, n, 6)
+            assert len(mine) == len(orc) == 5
+            for j in range(5):
+                want = golden["dil/%d/%s/%d" % (i, k1, j + 1)]
+                for got in (mine[j], orc[j]):
+                    uv = np.stack([np.asarray(got["u"], np.int64), np.asarray(got["v"], np.int64)], 1)
+                    uv = uv[np.lexsort((uv[:, 1], uv[:, 0]))]
+                    assert np.array_equal(uv, want), (i, k1, j + 1)
+                # and they are what the scene generator put into the scene
+                stored = sc["graph"][k1][j + 1]
+                suv = np.stack([np.asarray(stored["u"], np.int64), np.asarray(stored["v"], np.int64)], 1)
+                assert np.array_equal(suv[np.lexsort((suv[:, 1], suv[:, 0]))], want)
+                seen += 1
+    assert seen == 40
