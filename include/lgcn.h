@@ -321,6 +321,34 @@ int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs,
                    const float *gc, const float *btc,
                    float eps, int mma, float *m, void *stream);
 
+/*
+ * Att.forward for given pairs in ONE launch per tile of target rows (lanegcn.py:691-709): query path, per-pair MLP,
+ * segment sum over the target's pairs (hi is sorted: contiguous), node epilogue.  Same arithmetic as
+ * lgcn_agg_mlp_pair (U) + lgcn_att_pairs + lgcn_agg_mlp (tail), but the pair rows m_p stay on the CU:
+ *   U[t]  = ReLU(GN_q(W_q a[t])) W_c0q^T            W_c0q = ctx.0 columns 128..255
+ *   m_p   = ReLU(GN_c(W_c0e e_p + U[hi_p] + V[wi_p]))   e_p as in lgcn_att_pairs, V [S,128] from the caller
+ *   out[t] = ReLU(GN_l(W_lin ReLU(GN_n(W_agt a[t] + W_c1 sum_{p: hi_p = t} m_p))) + a[t])
+ * rowptr [T+1]: rowptr[t] = first pair with hi >= t (lgcn_pairs_build), rowptr[T] = P; values are clamped to cap.
+ * targets_per_block: 8, 16 or 32 target rows (and all their pairs) per workgroup: small for few targets with many
+ * pairs each (A2A), 32 for many targets with few pairs (A2M).  Split-precision modes only (F32: LGCN_ESHAPE).
+ * The segment sums are formed in pair order by one thread group per target: no atomics, bitwise repeatable.
+ */
+typedef struct {
+    const float *agts;                /* [T,128] target rows (also the residual) */
+    int64_t n_agt;
+    const float *agt_ctrs, *ctx_ctrs; /* [T,2], [S,2] */
+    const int32_t *hi, *wi, *rowptr;
+    int64_t cap;
+    const float *wpq, *gq, *bq, *wpc0q;
+    const float *wd0, *bd0, *wpd2, *gd, *btd, *wpc0e, *V, *gc, *btc;
+    const float *wpagt, *wpc1, *gn, *bn, *wplin, *gl, *bl;
+    float eps;
+    int32_t mma;
+    int32_t targets_per_block;
+    float *out;                       /* [T,128] */
+} lgcn_att_fused_t;
+int lgcn_att_fused(const lgcn_att_fused_t *p_host, void *stream);
+
 /* ------------------------------------------------------------------ */
 /* Backward building blocks (fp32; the row-GEMMs of the backward are     */
 /* lgcn_agg_mlp launches on transposed plans / transposed weights)       */

@@ -58,6 +58,14 @@ class LaneConv(C.Structure):      # lgcn_laneconv_t
     ]
 
 
+class AttFused(C.Structure):      # lgcn_att_fused_t
+    _fields_ = ([("agts", C.c_void_p), ("n_agt", C.c_int64), ("agt_ctrs", C.c_void_p), ("ctx_ctrs", C.c_void_p),
+                 ("hi", C.c_void_p), ("wi", C.c_void_p), ("rowptr", C.c_void_p), ("cap", C.c_int64)]
+                + [(n, C.c_void_p) for n in ("wpq", "gq", "bq", "wpc0q", "wd0", "bd0", "wpd2", "gd", "btd", "wpc0e", "V",
+                                             "gc", "btc", "wpagt", "wpc1", "gn", "bn", "wplin", "gl", "bl")]
+                + [("eps", C.c_float), ("mma", C.c_int32), ("targets_per_block", C.c_int32), ("out", C.c_void_p)])
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); every symbol include/lgcn.h declares
@@ -91,6 +99,7 @@ SIGNATURES = {
     "lgcn_gather_rows": (C.c_int, [_P, _P, _P, _L, _P, _P]),
     "lgcn_gather_sum": (C.c_int, [_P, _P, _P, _L, _P, _P]),
     "lgcn_pair_add": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _P, _P]),
+    "lgcn_att_fused": (C.c_int, [C.POINTER(AttFused), _P]),
     "lgcn_check_finite": (C.c_int, [_P, _L, _P, _L, _P, _I, _P]),
     "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
     "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),

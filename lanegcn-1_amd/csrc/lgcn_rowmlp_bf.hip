@@ -483,27 +483,6 @@ __global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, false, F) void k_agg_m
     else agg_body<RB, F, 0, false>(pb, tiles_b, blockIdx.x - tiles_a, smem);
 }
 
-// ------------------------------------------------------- shared pieces -----
-// h1[row][c] = ReLU(w1[c][0] x + w1[c][1] y + b1[c]) for the thread's 16 channels, split into planes
-template <int F>
-__device__ __forceinline__ void lin2_relu_split(uint16_t *planes, int plane_elems, int row, int t, float x, float y,
-                                                const float *__restrict__ w1, const float *__restrict__ b1) {
-    const int c0 = 4 * (t & 7);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int c = c0 + 32 * j;
-        const float4 wa = *reinterpret_cast<const float4 *>(w1 + 2 * c);
-        const float4 wb = *reinterpret_cast<const float4 *>(w1 + 2 * c + 4);
-        const float4 bb = *reinterpret_cast<const float4 *>(b1 + c);
-        float4 o;
-        o.x = relu_nan(x * wa.x + y * wa.y + bb.x);
-        o.y = relu_nan(x * wa.z + y * wa.w + bb.y);
-        o.z = relu_nan(x * wb.x + y * wb.y + bb.z);
-        o.w = relu_nan(x * wb.z + y * wb.w + bb.w);
-        split_store<F>(planes, plane_elems, row, c, o);
-    }
-}
-
 template <int RB, int F>
 __global__ __launch_bounds__(256) void k_mapnet_input_bf(const InputParams p, int n_tiles) {
     using TL = Tile<RB, F>;

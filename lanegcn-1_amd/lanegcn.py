@@ -388,6 +388,16 @@ class Att(nn.Module):
         T = agts.shape[0]
         lin = self.linear
         c0 = self.ctx[0]
+        if ops.att_impl() == "fused" and ops.get_mma() != "f32" and side is None and ctx.shape[0] > 0:
+            # one launch per tile of targets: query path, pair MLP, segment sum and epilogue (lgcn_att_fused); the
+            # per-context V = ctx W_c0[:,256:384]^T is its own small GEMM
+            V = ops.agg_mlp(ctx.shape[0], [ops.RelSpec(ctx, ops.packed(c0.linear.weight, 256, 128))], 0)
+            return ops.att_fused(agts, ps, V, ops.packed(self.query.linear.weight), _gn(self.query.norm),
+                                 ops.packed(c0.linear.weight, 128, 128), self.dist[0].weight, self.dist[0].bias,
+                                 ops.packed(self.dist[2].linear.weight), _gn(self.dist[2].norm),
+                                 ops.packed(c0.linear.weight, 0, 128), _gn(c0.norm), ops.packed(self.agt.weight),
+                                 ops.packed(self.ctx[1].weight), _gn(self.norm), ops.packed(lin.linear.weight),
+                                 _gn(lin.norm), eps=self.norm.eps)
         # row-wise Linears commute with the gathers agts[hi] / ctx[wi]: evaluate them per node.  U (per target:
         # query -> GN -> ReLU -> ctx.0[:,128:256]) and V (per context row: ctx.0[:,256:384]) are independent:
         # one dual-problem launch

@@ -583,6 +583,21 @@ def set_lc_variant(v: int):
     _lc_variant_forced = int(v)
 
 _lc_impl = os.environ.get("LGCN_LANECONV", "tiled")
+# Att layer for a given pair set: "split" (default) = U/V GEMMs + per-pair MLP (writes m [cap,128]) + segment-sum
+# tail, three wide launches; "fused" = lgcn_att_fused, one launch per tile of targets that keeps the pair rows on
+# the CU: no [cap,128] buffer (0.3-1.6 GB per call on large batches), measured 1.2-1.6x slower at S2.
+_att_impl = os.environ.get("LGCN_ATT", "split")
+
+
+def set_att_impl(name: str):
+    global _att_impl
+    if name not in ("fused", "split"):
+        raise L.LgcnError("att impl must be 'fused' or 'split'")
+    _att_impl = name
+
+
+def att_impl() -> str:
+    return _att_impl
 
 
 def set_laneconv_impl(name: str):
@@ -703,6 +718,37 @@ def att_pairs(ps: PairSet, wd0, bd0, wpd2, gn_d, wpc0e, U, V, gn_c, m=None, eps=
                                 _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _mma, _ptr(m), _stream())
     L.check(rc, "lgcn_att_pairs")
     return m
+
+
+def att_targets_per_block(n_agt: int, device) -> int:
+    """Target rows per workgroup of att_fused: as many as still give the chip ~a workgroup per CU (8..32)."""
+    forced = int(os.environ.get("LGCN_ATT_TT", "0"))        # tests / tuning
+    if forced:
+        return forced
+    per = n_agt / max(1, cu_count(device))
+    return 32 if per >= 24 else 16 if per >= 12 else 8      # lgcn_att_fused also takes 4
+
+
+def att_fused(agts, ps: PairSet, V, wq, gn_q, wc0q, wd0, bd0, wd2, gn_d, wc0e, gn_c, wagt, wc1, gn_n, wlin, gn_l,
+              eps=EPS, targets_per_block: Optional[int] = None, tag="att_fused"):
+    """One Att layer for a given pair set (lgcn_att_fused): packed weights w*, (gamma, beta) pairs gn_*."""
+    lib = L.load()
+    agts = _dev(agts, torch.float32, "agts")
+    out = torch.empty_like(agts)
+    p = L.AttFused()
+    p.agts, p.n_agt, p.agt_ctrs, p.ctx_ctrs = agts.data_ptr(), agts.shape[0], ps.agt_ctrs.data_ptr(), ps.ctx_ctrs.data_ptr()
+    p.hi, p.wi, p.rowptr, p.cap = ps.hi.data_ptr(), ps.wi.data_ptr(), ps.rowptr.data_ptr(), ps.cap
+    p.wpq, p.gq, p.bq, p.wpc0q = wq.data_ptr(), gn_q[0].data_ptr(), gn_q[1].data_ptr(), wc0q.data_ptr()
+    p.wd0, p.bd0, p.wpd2, p.gd, p.btd = wd0.data_ptr(), bd0.data_ptr(), wd2.data_ptr(), gn_d[0].data_ptr(), gn_d[1].data_ptr()
+    p.wpc0e, p.V, p.gc, p.btc = wc0e.data_ptr(), V.data_ptr(), gn_c[0].data_ptr(), gn_c[1].data_ptr()
+    p.wpagt, p.wpc1, p.gn, p.bn = wagt.data_ptr(), wc1.data_ptr(), gn_n[0].data_ptr(), gn_n[1].data_ptr()
+    p.wplin, p.gl, p.bl = wlin.data_ptr(), gn_l[0].data_ptr(), gn_l[1].data_ptr()
+    p.eps, p.mma = eps, _mma
+    p.targets_per_block = targets_per_block or att_targets_per_block(agts.shape[0], agts.device)
+    p.out = out.data_ptr()
+    with _Timed(tag):
+        L.check(lib.lgcn_att_fused(C.byref(p), _stream()), "lgcn_att_fused")
+    return out
 
 
 # ------------------------------------------------------------------ backward building blocks

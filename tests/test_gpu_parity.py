@@ -647,3 +647,25 @@ def test_gn_cl_channels_last_layout(hip, shape):
         got = ops.gn_cl(xc, gn.weight.cuda(), gn.bias.cuda(), gn.eps, res=coarse.cuda().contiguous(memory_format=cl),
                         res_up2=True)
         assert float((got.cpu().double() - (up + ref)).abs().max()) <= 2e-5
+
+
+def test_att_fused_launch_vs_reference_captures(gcase, golden, hip, mma_mode):
+    """The memory-lean Att implementation (lgcn_att_fused: one launch per tile of targets, pair rows never written
+    to HBM) against the reference's stage captures, for every tile width; same 1e-4 bar as the default."""
+    M, ops = hip
+    if mma_mode == "f32":
+        pytest.skip("split-precision kernel")
+    scenes, _, mods = gcase
+    actors = torch.from_numpy(golden["actors_in"])
+    ops.set_att_impl("fused")
+    try:
+        for tt in (4, 8, 16, 32):
+            import os
+            os.environ["LGCN_ATT_TT"] = str(tt)
+            out, _ = run_hot_path(M, mods, scenes, actors)
+            for k in ("a2m", "m2m", "m2a", "a2a"):
+                err = float(np.abs(out[k] - golden[k]).max())
+                assert err <= FTOL, (tt, k, err)
+    finally:
+        os.environ.pop("LGCN_ATT_TT", None)
+        ops.set_att_impl("split")
