@@ -435,7 +435,7 @@ int lgcn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev,
  * bf16's 3.4e38); an operand beyond that becomes +-inf planes, whose products cancel to NaN, and every ReLU of this
  * library keeps a NaN a NaN (like ATen's), so the row it belongs to -- and every row fed by it -- reaches the stage
  * output as NaN rather than as plausible numbers.  lgcn_check_finite looks for that on the device:
- *   flag[0] |= bit  if any of a[0..na) or b[0..nb) is not finite   (na, nb multiples of 4; flag zeroed by the caller).
+ *   flag[0] |= bit  if any of a[0..na) or b[0..nb) is not finite   (a, b 16-byte aligned; flag zeroed by the caller).
  * The host side reads the flag once per forward and re-runs a flagged forward in LGCN_MMA_BF16X3 (ops.py: guarded).
  */
 int lgcn_check_finite(const float *a, int64_t na, const float *b, int64_t nb, int32_t *flag, int bit, void *stream);

@@ -335,15 +335,21 @@ __global__ __launch_bounds__(256) void k_pair_add(const float4 *__restrict__ c, 
 // tensors per launch.  The 16-bit-plane matrix modes have fp16's / bf16's range: an overflow shows up as NaN rows
 // in the stage outputs (the kernels' ReLU keeps NaN), this is how a caller looks for them without a device->host
 // copy of the features.
-__global__ __launch_bounds__(256) void k_check_finite(const float4 *__restrict__ a, int64_t na4, const float4 *__restrict__ b,
-                                                      int64_t nb4, int32_t *flag, int bit) {
+__global__ __launch_bounds__(256) void k_check_finite(const float *__restrict__ a, int64_t na, const float *__restrict__ b,
+                                                      int64_t nb, int32_t *flag, int bit) {
     bool bad = false;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < na4 + nb4; i += stride) {
-        const float4 v = i < na4 ? a[i] : b[i - na4];
-        // finite <=> exponent field below all-ones: (v - v) is 0 for finite v and NaN otherwise
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // finite <=> (v - v) == 0 (inf - inf and NaN - NaN are NaN); whole float4s first, then the <= 3 leftover floats
+    const int64_t na4 = na >> 2, nb4 = nb >> 2;
+    for (int64_t i = i0; i < na4 + nb4; i += stride) {
+        const float4 v = i < na4 ? reinterpret_cast<const float4 *>(a)[i] : reinterpret_cast<const float4 *>(b)[i - na4];
         const float t = (v.x - v.x) + (v.y - v.y) + (v.z - v.z) + (v.w - v.w);
         bad |= !(t == 0.f);
+    }
+    const int64_t ra = na - 4 * na4, rb = nb - 4 * nb4;
+    if (i0 < ra + rb) {
+        const float v = i0 < ra ? a[4 * na4 + i0] : b[4 * nb4 + (i0 - ra)];
+        bad |= !((v - v) == 0.f);
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
 }
@@ -466,15 +472,15 @@ int lgcn_gather_rows(const float *src, const int32_t *idx, const int32_t *n_dev,
 }
 
 int lgcn_check_finite(const float *a, int64_t na, const float *b, int64_t nb, int32_t *flag, int bit, void *stream) {
-    if (na < 0 || nb < 0 || (na & 3) || (nb & 3) || bit == 0) return LGCN_EINVAL;
+    if (na < 0 || nb < 0 || bit == 0) return LGCN_EINVAL;
     if (na + nb == 0) return LGCN_OK;
     LGCN_CHECK_PTR(flag);
     if (na) { LGCN_CHECK_PTR(a); LGCN_CHECK_ALIGN16(a); }
     if (nb) { LGCN_CHECK_PTR(b); LGCN_CHECK_ALIGN16(b); }
     int64_t blocks = ((na + nb) / 4 + 1023) / 1024;      // four float4 per thread
+    if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_check_finite, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4 *>(a), na / 4, reinterpret_cast<const float4 *>(b), nb / 4, flag, bit);
+    hipLaunchKernelGGL(k_check_finite, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, na, b, nb, flag, bit);
     return launch_status();
 }
 

@@ -44,10 +44,27 @@ def from_numpy(data):
     return data
 
 
+class Batch(dict):
+    """The reference's batch -- a dict of per-scene lists (data.py:555-561) -- that also carries, as an ATTRIBUTE
+    (the dict's keys stay exactly the reference's), the same scenes packed for the device: ``flat`` =
+    (engine.HostFlatBatch, (actor tracks, rot, orig, actors per scene))."""
+    flat = None
+
+
 def collate_fn(batch):
-    """list of scene dicts -> dict of per-key lists, no padding (reference data.py:555-561)."""
+    """list of scene dicts -> dict of per-key lists, no padding (reference data.py:555-561).  The packed copy
+    (Batch.flat: one staging buffer) is built here -- i.e. in the DataLoader worker when there is one -- so that
+    Net.forward(data) under no_grad starts with one host-to-device copy instead of a host collate."""
+    raw = batch
     batch = from_numpy(batch)
-    return {k: [scene[k] for scene in batch] for k in batch[0].keys()}
+    out = Batch({k: [scene[k] for scene in batch] for k in batch[0].keys()})
+    try:
+        from .engine import collate_flat_host, host_actor_inputs
+        if len(raw) > 0 and all(k in raw[0] for k in ("graph", "feats", "ctrs", "rot", "orig")):
+            out.flat = (collate_flat_host(raw, pin=False), host_actor_inputs(raw))
+    except Exception:      # noqa: BLE001 -- the packed copy is an accelerator, never a requirement
+        out.flat = None
+    return out
 
 
 # ---------------------------------------------------------------- synthetic scenes

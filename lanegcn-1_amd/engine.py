@@ -39,16 +39,40 @@ class FlatBatch:
     cap_a2m: int                # sum_i n_i * a_i   (upper bound of the pair counts)
     cap_a2a: int                # sum_i a_i * a_i
     n_edges: List[int]
+    _buf: Optional[torch.Tensor] = None     # the one device byte buffer the arrays are views of (collate_flat)
+
+    def buf_view(self) -> Optional[torch.Tensor]:
+        return self._buf
 
 
-def collate_flat(scenes: List[Dict], device=None, pin: bool = False) -> FlatBatch:
-    """Host collate of scene dicts (numpy or CPU torch leaves) into a FlatBatch on `device`.
-    Every tensor is its own device allocation on purpose: packing them as views of three staging buffers (one
-    host-to-device copy per dtype) was measured to cost nothing on the host side but halved the throughput of four
-    captured forwards in flight (106 k -> 52 k scenes/s; cause not isolated), so it was reverted.
-    pin: stage through pinned memory (asynchronous copies; allocating pinned buffers per call costs more than
-    it saves for these ~2 MB batches, so a loader that wants it should reuse its own staging buffers)."""
-    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+_FLAT_ARRAYS = ("node_ctrs", "node_feats", "turn", "control", "intersect", "actor_ctrs", "node_off", "actor_off",
+                "idx_local", "seg_off", "seg_base")
+
+
+@dataclass
+class HostFlatBatch:
+    """One batch of scenes, flat, on the HOST: every array of FlatBatch packed at 256-byte aligned offsets into ONE
+    byte buffer (pinned when a GPU is present), so that uploading a batch is one host-to-device copy
+    (the reference does ~1.3 k per batch, utils.py:74-96).  Built by ``collate_flat_host`` -- plain
+    numpy, so a DataLoader worker can do it (``collate_fn`` of this package attaches it as data["_flat"])."""
+    buf: torch.Tensor                      # uint8 [nbytes]
+    layout: Dict[str, tuple]               # name -> (offset, numpy dtype str, shape)
+    meta: Dict                             # the non-array fields of FlatBatch
+
+    def to(self, device=None) -> "FlatBatch":
+        """Upload (one copy) and cut the device buffer into FlatBatch views (256-byte aligned)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        dbuf = self.buf if dev.type == "cpu" else self.buf.to(dev, non_blocking=True)
+        arrs = {}
+        for name, (off, dt, shape) in self.layout.items():
+            cnt = int(np.prod(shape)) if len(shape) else 1
+            tdt = {"float32": torch.float32, "int32": torch.int32, "int64": torch.int64}[dt]
+            arrs[name] = dbuf[off:off + cnt * np.dtype(dt).itemsize].view(tdt).view(*shape)
+        return FlatBatch(**self.meta, **arrs, _buf=dbuf)
+
+
+def collate_flat_host(scenes: List[Dict], pin: Optional[bool] = None) -> HostFlatBatch:
+    """Host collate of scene dicts (numpy or CPU torch leaves) into one staging buffer."""
 
     def npy(x):
         return x.numpy() if torch.is_tensor(x) else np.asarray(x)
@@ -70,7 +94,7 @@ def collate_flat(scenes: List[Dict], device=None, pin: bool = False) -> FlatBatc
         nonlocal pos
         begin = pos
         for j, g in enumerate(graphs):
-            x = npy(getter(g)).astype(np.int64).reshape(-1)   # 0-dim guard (lanegcn.py:203-207) + to_long
+            x = npy(getter(g)).astype(np.int64, copy=False).reshape(-1)   # 0-dim guard (lanegcn.py:203-207) + to_long
             pieces.append(x)
             seg_len.append(len(x))
             seg_base.append(node_off[j])
@@ -93,24 +117,50 @@ def collate_flat(scenes: List[Dict], device=None, pin: bool = False) -> FlatBatc
     seg_off = np.zeros(len(seg_len) + 1, np.int64)
     np.cumsum(seg_len, out=seg_off[1:])
 
-    def up(a, dtype=None):
-        t = torch.from_numpy(np.ascontiguousarray(a if dtype is None else a.astype(dtype)))
-        if dev.type == "cpu":
-            return t
-        return t.pin_memory().to(dev, non_blocking=True) if pin else t.to(dev)
-
     cat = lambda key, src: np.concatenate([npy(s[key]) for s in src], 0)
-    return FlatBatch(
-        n_scenes=B, n_nodes=int(node_off[-1]), n_actors=int(actor_off[-1]), num_scales=ns,
-        node_ctrs=up(cat("ctrs", graphs), np.float32), node_feats=up(cat("feats", graphs), np.float32),
-        turn=up(cat("turn", graphs), np.float32), control=up(cat("control", graphs), np.float32),
-        intersect=up(cat("intersect", graphs), np.float32), actor_ctrs=up(cat("ctrs", scenes), np.float32),
-        node_off=up(node_off, np.int32), actor_off=up(actor_off, np.int32),
-        idx_local=up(np.concatenate(pieces) if pieces else np.zeros(0, np.int64)),
-        seg_off=up(seg_off), seg_base=up(np.asarray(seg_base, np.int64)),
-        rel_slices=rel_slices, cap_a2m=int(np.dot(n_nodes, n_act)), cap_a2a=int(np.dot(n_act, n_act)),
-        n_edges=n_edges,
-    )
+    arrays = {
+        "node_ctrs": cat("ctrs", graphs).astype(np.float32, copy=False), "node_feats": cat("feats", graphs).astype(np.float32, copy=False),
+        "turn": cat("turn", graphs).astype(np.float32, copy=False), "control": cat("control", graphs).astype(np.float32, copy=False),
+        "intersect": cat("intersect", graphs).astype(np.float32, copy=False), "actor_ctrs": cat("ctrs", scenes).astype(np.float32, copy=False),
+        "node_off": node_off.astype(np.int32), "actor_off": actor_off.astype(np.int32),
+        "idx_local": np.concatenate(pieces) if pieces else np.zeros(0, np.int64),
+        "seg_off": seg_off, "seg_base": np.asarray(seg_base, np.int64),
+    }
+    layout, off = {}, 0
+    for name in _FLAT_ARRAYS:
+        a = arrays[name]
+        layout[name] = (off, str(a.dtype), tuple(a.shape))
+        off = (off + a.nbytes + 255) & ~255
+    pin = torch.cuda.is_available() if pin is None else pin
+    buf = torch.empty(max(off, 256), dtype=torch.uint8, pin_memory=bool(pin))
+    view = buf.numpy()
+    for name in _FLAT_ARRAYS:
+        o, _, _ = layout[name]
+        a = np.ascontiguousarray(arrays[name])
+        view[o:o + a.nbytes] = a.view(np.uint8).reshape(-1)
+    meta = dict(n_scenes=B, n_nodes=int(node_off[-1]), n_actors=int(actor_off[-1]), num_scales=ns,
+                rel_slices=rel_slices, cap_a2m=int(np.dot(n_nodes, n_act)), cap_a2a=int(np.dot(n_act, n_act)),
+                n_edges=n_edges)
+    return HostFlatBatch(buf, layout, meta)
+
+
+def collate_flat(scenes: List[Dict], device=None, pin: Optional[bool] = None) -> FlatBatch:
+    """Host collate of scene dicts into a FlatBatch on `device`: one staging buffer, ONE host-to-device copy.
+    (Round 1 reported that packing the arrays as views of staging buffers halved the throughput of four captured
+    forwards in flight; with every view 256-byte aligned in one buffer that does not reproduce: DESIGN.md 5c.)"""
+    on_cpu = device is not None and torch.device(device).type == "cpu"
+    return collate_flat_host(scenes, pin=False if on_cpu else pin).to(device)
+
+
+def host_actor_inputs(scenes):
+    """[A,3,20] actor tracks (actor_gather, lanegcn.py:155-168) and the per-actor world-frame transform rot [A,2,2] /
+    orig [A,2] (the scene's, repeated for its actors) as host tensors + the actors-per-scene list."""
+    npy = lambda x: x.numpy() if torch.is_tensor(x) else np.asarray(x)
+    feats = np.concatenate([npy(s["feats"]).transpose(0, 2, 1) for s in scenes], 0).astype(np.float32)
+    rot = np.concatenate([np.repeat(npy(s["rot"])[None], len(s["ctrs"]), 0) for s in scenes]).astype(np.float32)
+    orig = np.concatenate([np.repeat(npy(s["orig"])[None], len(s["ctrs"]), 0) for s in scenes]).astype(np.float32)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    return t(feats), t(rot), t(orig), [len(s["ctrs"]) for s in scenes]
 
 
 class HotPathEngine:
@@ -283,15 +333,10 @@ class FullNetEngine:
 
     @staticmethod
     def actor_inputs(scenes, device=None):
-        """[A,3,20] actor tracks (actor_gather, lanegcn.py:155-168) and the per-actor world-frame transform
-        rot [A,2,2] / orig [A,2] (the scene's, repeated for its actors: no host data inside the captured forward)."""
+        """Device copies of host_actor_inputs(scenes): (feats [A,3,20], rot [A,2,2], orig [A,2])."""
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        npy = lambda x: x.numpy() if torch.is_tensor(x) else np.asarray(x)
-        feats = np.concatenate([npy(s["feats"]).transpose(0, 2, 1) for s in scenes], 0).astype(np.float32)
-        rot = np.concatenate([np.repeat(npy(s["rot"])[None], len(s["ctrs"]), 0) for s in scenes]).astype(np.float32)
-        orig = np.concatenate([np.repeat(npy(s["orig"])[None], len(s["ctrs"]), 0) for s in scenes]).astype(np.float32)
-        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-        return up(feats), up(rot), up(orig)
+        feats, rot, orig, _ = host_actor_inputs(scenes)
+        return feats.to(dev), rot.to(dev), orig.to(dev)
 
     @torch.no_grad()
     def forward(self, fb: FlatBatch, actor_feats: torch.Tensor, rot: torch.Tensor, orig: torch.Tensor,
@@ -317,7 +362,7 @@ class FullNetEngine:
             res["n_pairs"] = hot["n_pairs"]     # device counts of the three pair sets (A2M, M2A, A2A)
         return res
 
-    def capture(self, fb, actor_feats, rot, orig, sizes, warmup: int = 3, tune_convs: bool = True):
+    def capture(self, fb, actor_feats, rot, orig, sizes, warmup: int = 3, tune_convs: bool = True, **fwd_kw):
         """Capture the whole Net forward.  tune_convs: let MIOpen search its solvers for ActorNet's 17 Conv1d shapes
         during the warm-up (torch.backends.cudnn.benchmark): the shapes of a captured graph are fixed, and the
         default heuristic picks were measured 11 % slower end to end (2.34 vs 2.10 ms per batch)."""
@@ -328,12 +373,12 @@ class FullNetEngine:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):
-                    self.forward(fb, actor_feats, rot, orig, sizes)
+                    self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                out = self.forward(fb, actor_feats, rot, orig, sizes)
+                out = self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
         finally:
             torch.backends.cudnn.benchmark = prev
         return graph, out

@@ -642,6 +642,31 @@ class PredNet(nn.Module):
         return {"cls": [cls[i] for i in actor_idcs], "reg": [reg[i] for i in actor_idcs]}
 
 
+def _net_replay_or_run(self, eng, fb, feats, rot, orig, sizes):
+    """Whole-Net forward for one flat batch.  A batch whose shapes (and the weights' versions) equal the previous
+    call's is captured in a hipGraph once and replayed from then on (fixed-size evaluation batches: ~120 eager
+    launches become one replay plus one input copy); anything else runs eagerly.  Net.graph_cache = False disables it."""
+    if not Net.graph_cache:
+        return eng.forward(fb, feats, rot, orig, sizes, return_pairs=Att.strict)
+    sig = (fb.n_nodes, fb.n_actors, tuple(fb.n_edges), tuple(sizes), fb.cap_a2m, fb.cap_a2a, ops.get_mma(),
+           ops.att_impl(), ops.laneconv_impl(), Att.strict, sum(p._version for p in ops.module_params(self)))
+    st = self.__dict__.setdefault("_graph_state", {"last": None, "sig": None, "graph": None})
+    if st["graph"] is not None and st["sig"] == sig:
+        g, gfb, gin, gout = st["graph"]
+        for dst, src in zip((gfb.buf_view(), *gin), (fb.buf_view(), feats, rot, orig)):
+            dst.copy_(src, non_blocking=True)
+        g.replay()
+        return gout
+    if st["last"] == sig and fb.buf_view() is not None:      # second time in a row: worth capturing
+        gin = (feats.clone(), rot.clone(), orig.clone())
+        g, gout = eng.capture(fb, *gin, sizes, warmup=1, tune_convs=False, return_pairs=Att.strict)
+        st.update(sig=sig, graph=(g, fb, gin, gout))
+        g.replay()
+        return gout
+    st["last"] = sig
+    return eng.forward(fb, feats, rot, orig, sizes, return_pairs=Att.strict)
+
+
 class Net(nn.Module):
     """ActorNet -> [graph_gather -> MapNet -> A2M -> M2M -> M2A -> A2A] -> PredNet (reference lanegcn.py:94-151).
     The bracketed part is the HIP hot path; input and output formats are the reference's."""
@@ -677,6 +702,9 @@ class Net(nn.Module):
             out["reg"][i] = torch.matmul(out["reg"][i], rot[i]) + orig[i].view(1, 1, 1, -1)
         return out
 
+    graph_cache = True
+    _replay_or_run = _net_replay_or_run
+
     def _forward_inference(self, data: Dict) -> Dict[str, List[Tensor]]:
         """No-grad fast path of forward(): the batch is collated flat on the host (one H2D per array) and run
         through engine.FullNetEngine -- same arithmetic and same outputs as the module path, without its
@@ -687,18 +715,25 @@ class Net(nn.Module):
         if eng is None:
             eng = FullNetEngine(self)
             self.__dict__["_engine"] = eng
-        n = len(data["feats"])
-        scenes = [{k: data[k][i] for k in ("feats", "ctrs", "rot", "orig", "graph")} for i in range(n)]
-        cpu = lambda t: t.cpu() if torch.is_tensor(t) and t.is_cuda else t
-        scenes = [{"feats": cpu(s["feats"]), "ctrs": cpu(s["ctrs"]), "rot": cpu(s["rot"]), "orig": cpu(s["orig"]),
-                   "graph": _tree_cpu(s["graph"])} for s in scenes]
-        fb = collate_flat(scenes)
+        flat = getattr(data, "flat", None)
+        if flat is not None:      # packed by this package's collate_fn (in the DataLoader worker): one H2D copy
+            hfb, (feats, rot, orig, sizes) = flat
+            fb = hfb.to()
+            dev = fb.node_ctrs.device
+            feats, rot, orig = feats.to(dev, non_blocking=True), rot.to(dev, non_blocking=True), orig.to(dev, non_blocking=True)
+        else:
+            n = len(data["feats"])
+            scenes = [{k: data[k][i] for k in ("feats", "ctrs", "rot", "orig", "graph")} for i in range(n)]
+            cpu = lambda t: t.cpu() if torch.is_tensor(t) and t.is_cuda else t
+            scenes = [{"feats": cpu(s["feats"]), "ctrs": cpu(s["ctrs"]), "rot": cpu(s["rot"]), "orig": cpu(s["orig"]),
+                       "graph": _tree_cpu(s["graph"])} for s in scenes]
+            fb = collate_flat(scenes)
+            feats, rot, orig = eng.actor_inputs(scenes)
+            sizes = [len(s["ctrs"]) for s in scenes]
         ns = fb.num_scales
         if fb.n_nodes == 0 or fb.n_edges[2 * ns - 2] == 0 or fb.n_edges[2 * ns - 1] == 0:
             raise KeyError("node_idcs")
-        feats, rot, orig = eng.actor_inputs(scenes)
-        sizes = [len(s["ctrs"]) for s in scenes]
-        out = eng.forward(fb, feats, rot, orig, sizes, return_pairs=Att.strict)
+        out = self._replay_or_run(eng, fb, feats, rot, orig, sizes)
         if ops.get_guard() != "off" and ops.get_mma() == "f16x2" and int(out["nonfinite"].item()) != 0:
             # an operand left fp16's range: the forward comes back with NaN rows; policy = re-run in bf16x3 or raise
             if ops.get_guard() == "raise":

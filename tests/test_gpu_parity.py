@@ -669,3 +669,33 @@ def test_att_fused_launch_vs_reference_captures(gcase, golden, hip, mma_mode):
     finally:
         os.environ.pop("LGCN_ATT_TT", None)
         ops.set_att_impl("split")
+
+
+def test_net_forward_graph_cache(golden, ref_state_names, hip):
+    """Drop-in Net.forward(data) under no_grad: eager, then captured on the second identical-shape call, then
+    replayed -- same outputs each time; a batch of another shape in between runs eagerly; a weight update drops
+    the captured graph."""
+    M, _ = hip
+    from lanegcn_amd import data as gen
+    net = M.Net(M.config)
+    net.load_state_dict(O.seeded_state(ref_state_names, int(golden["seed"])), strict=True)
+    net = net.cuda().eval()
+    scenes = load_scenes(golden)
+    batch, other = gen.collate_fn(scenes), gen.collate_fn(scenes[:3])
+    with torch.no_grad():
+        outs = [net(batch) for _ in range(4)]                      # eager, eager -> capture, replay, replay
+        assert net.__dict__["_graph_state"]["graph"] is not None
+        close = lambda a, b: torch.allclose(a, b, rtol=1e-5, atol=2e-4)
+        for i in range(len(scenes)):      # eager vs captured: same arithmetic up to the stock ops' (MIOpen, sort) own noise
+            assert close(outs[3]["cls"][i], outs[0]["cls"][i]) and close(outs[3]["reg"][i], outs[0]["reg"][i])
+        keep = [[t.clone() for t in outs[3]["reg"]], [t.clone() for t in outs[3]["cls"]]]
+        o3 = net(other)                                            # other shapes: eager, the captured graph stays
+        assert len(o3["cls"]) == 3 and net.__dict__["_graph_state"]["graph"] is not None
+        o4 = net(batch)                                            # replayed again (ActorNet's stock convolutions are
+        for i in range(len(scenes)):                               # not bitwise repeatable: 1 ulp of a ~1000 m coordinate)
+            assert close(o4["reg"][i], keep[0][i]) and close(o4["cls"][i], keep[1][i])
+        for i in range(len(scenes)):
+            assert float(np.abs(o4["cls"][i].cpu().numpy() - golden["net/cls/%d" % i]).max()) <= 2e-4
+        net.pred_net.cls[1].weight.add_(0.01)                     # a weight changed: replaying would be stale
+        o5 = net(batch)
+        assert not torch.equal(o5["cls"][0], keep[1][0])

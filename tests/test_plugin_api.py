@@ -50,6 +50,9 @@ def test_collate_and_actor_gather(M):
     assert set(batch) >= {"feats", "ctrs", "graph", "rot", "orig", "gt_preds", "has_preds"}
     assert all(isinstance(v, list) and len(v) == 3 for v in batch.values())
     assert torch.is_tensor(batch["graph"][0]["pre"][5]["u"])
+    # the packed copy for the device rides along as an attribute, not as a key
+    hfb, (tracks, rot, orig, sizes) = batch.flat
+    assert sizes == [50, 50, 50] and tracks.shape == (150, 3, 20) and hfb.meta["n_nodes"] == 972
     feats, idcs = M.actor_gather(batch["feats"])
     assert feats.shape == (150, 3, 20)
     assert [x.tolist() for x in idcs] == [list(range(50 * i, 50 * i + 50)) for i in range(3)]
