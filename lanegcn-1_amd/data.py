@@ -61,7 +61,9 @@ def collate_fn(batch):
     try:
         from .engine import collate_flat_host, host_actor_inputs
         if len(raw) > 0 and all(k in raw[0] for k in ("graph", "feats", "ctrs", "rot", "orig")):
-            out.flat = (collate_flat_host(raw, pin=False), host_actor_inputs(raw))
+            # pinned staging only in a process that already talks to the GPU (never initialise it in a loader worker)
+            pin = torch.cuda.is_available() and torch.cuda.is_initialized() and torch.utils.data.get_worker_info() is None
+            out.flat = (collate_flat_host(raw, pin=pin), host_actor_inputs(raw))
     except Exception:      # noqa: BLE001 -- the packed copy is an accelerator, never a requirement
         out.flat = None
     return out

@@ -642,29 +642,35 @@ class PredNet(nn.Module):
         return {"cls": [cls[i] for i in actor_idcs], "reg": [reg[i] for i in actor_idcs]}
 
 
-def _net_replay_or_run(self, eng, fb, feats, rot, orig, sizes):
-    """Whole-Net forward for one flat batch.  A batch whose shapes (and the weights' versions) equal the previous
-    call's is captured in a hipGraph once and replayed from then on (fixed-size evaluation batches: ~120 eager
-    launches become one replay plus one input copy); anything else runs eagerly.  Net.graph_cache = False disables it."""
-    if not Net.graph_cache:
-        return eng.forward(fb, feats, rot, orig, sizes, return_pairs=Att.strict)
-    sig = (fb.n_nodes, fb.n_actors, tuple(fb.n_edges), tuple(sizes), fb.cap_a2m, fb.cap_a2a, ops.get_mma(),
+def _net_replay_or_run(self, eng, hfb, feats, rot, orig, sizes):
+    """Whole-Net forward for one host-packed batch (engine.HostFlatBatch + host actor tensors).  A batch whose shapes
+    (and the weights' versions) equal the previous call's is captured in a hipGraph once and replayed from then on
+    (fixed-size evaluation batches: ~120 eager launches become one replay behind four input copies); anything else
+    is uploaded and run eagerly.  Net.graph_cache = False disables it."""
+    m = hfb.meta
+    sig = (m["n_nodes"], m["n_actors"], tuple(m["n_edges"]), tuple(sizes), m["cap_a2m"], m["cap_a2a"], ops.get_mma(),
            ops.att_impl(), ops.laneconv_impl(), Att.strict, sum(p._version for p in ops.module_params(self)))
     st = self.__dict__.setdefault("_graph_state", {"last": None, "sig": None, "graph": None})
-    if st["graph"] is not None and st["sig"] == sig:
+    if Net.graph_cache and st["graph"] is not None and st["sig"] == sig:
         g, gfb, gin, gout = st["graph"]
-        for dst, src in zip((gfb.buf_view(), *gin), (fb.buf_view(), feats, rot, orig)):
+        gfb.buf_view().copy_(hfb.buf, non_blocking=True)
+        for dst, src in zip(gin, (feats, rot, orig)):
             dst.copy_(src, non_blocking=True)
         g.replay()
-        return gout
-    if st["last"] == sig and fb.buf_view() is not None:      # second time in a row: worth capturing
-        gin = (feats.clone(), rot.clone(), orig.clone())
+        return gfb, gout
+    fb = hfb.to()
+    dev = fb.node_ctrs.device
+    ns = fb.num_scales
+    if fb.n_nodes == 0 or fb.n_edges[2 * ns - 2] == 0 or fb.n_edges[2 * ns - 1] == 0:
+        raise KeyError("node_idcs")
+    gin = tuple(t.to(dev, non_blocking=True) for t in (feats, rot, orig))
+    if Net.graph_cache and st["last"] == sig:      # second time in a row: worth capturing
         g, gout = eng.capture(fb, *gin, sizes, warmup=1, tune_convs=False, return_pairs=Att.strict)
         st.update(sig=sig, graph=(g, fb, gin, gout))
         g.replay()
-        return gout
+        return fb, gout
     st["last"] = sig
-    return eng.forward(fb, feats, rot, orig, sizes, return_pairs=Att.strict)
+    return fb, eng.forward(fb, *gin, sizes, return_pairs=Att.strict)
 
 
 class Net(nn.Module):
@@ -716,31 +722,33 @@ class Net(nn.Module):
             eng = FullNetEngine(self)
             self.__dict__["_engine"] = eng
         flat = getattr(data, "flat", None)
-        if flat is not None:      # packed by this package's collate_fn (in the DataLoader worker): one H2D copy
+        if flat is not None:      # packed by this package's collate_fn (in the DataLoader worker)
             hfb, (feats, rot, orig, sizes) = flat
-            fb = hfb.to()
-            dev = fb.node_ctrs.device
-            feats, rot, orig = feats.to(dev, non_blocking=True), rot.to(dev, non_blocking=True), orig.to(dev, non_blocking=True)
         else:
+            from .engine import collate_flat_host, host_actor_inputs
             n = len(data["feats"])
             scenes = [{k: data[k][i] for k in ("feats", "ctrs", "rot", "orig", "graph")} for i in range(n)]
             cpu = lambda t: t.cpu() if torch.is_tensor(t) and t.is_cuda else t
             scenes = [{"feats": cpu(s["feats"]), "ctrs": cpu(s["ctrs"]), "rot": cpu(s["rot"]), "orig": cpu(s["orig"]),
                        "graph": _tree_cpu(s["graph"])} for s in scenes]
-            fb = collate_flat(scenes)
-            feats, rot, orig = eng.actor_inputs(scenes)
-            sizes = [len(s["ctrs"]) for s in scenes]
-        ns = fb.num_scales
-        if fb.n_nodes == 0 or fb.n_edges[2 * ns - 2] == 0 or fb.n_edges[2 * ns - 1] == 0:
+            hfb = collate_flat_host(scenes)
+            feats, rot, orig, sizes = host_actor_inputs(scenes)
+        m = hfb.meta
+        ns = m["num_scales"]
+        if m["n_nodes"] == 0 or m["n_edges"][2 * ns - 2] == 0 or m["n_edges"][2 * ns - 1] == 0:
             raise KeyError("node_idcs")
-        out = self._replay_or_run(eng, fb, feats, rot, orig, sizes)
-        if ops.get_guard() != "off" and ops.get_mma() == "f16x2" and int(out["nonfinite"].item()) != 0:
+        fb, out = self._replay_or_run(eng, hfb, feats, rot, orig, sizes)
+        # one device->host read for both host-side checks: the range guard's flag and the pair counts
+        host = torch.cat([out["nonfinite"].view(1)] + ([c.view(1) for c in out["n_pairs"]] if Att.strict else [])).tolist()
+        if ops.get_guard() != "off" and ops.get_mma() == "f16x2" and host[0] != 0:
             # an operand left fp16's range: the forward comes back with NaN rows; policy = re-run in bf16x3 or raise
             if ops.get_guard() == "raise":
                 raise L.LgcnError("non-finite outputs in f16x2 mode: an operand left fp16's range (|x| >= 65504)")
+            dev = fb.node_ctrs.device
             with ops.mma_scope("bf16x3"):
-                out = eng.forward(fb, feats, rot, orig, sizes, return_pairs=Att.strict)
-        if Att.strict and any(int(c) == 0 for c in torch.stack(out["n_pairs"]).flatten().tolist()):
+                out = eng.forward(fb, feats.to(dev), rot.to(dev), orig.to(dev), sizes, return_pairs=Att.strict)
+            host = [0] + (torch.stack(out["n_pairs"]).flatten().tolist() if Att.strict else [])
+        if Att.strict and any(int(c) == 0 for c in host[1:]):
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
         cls, reg, st = [], [], 0
         for a in sizes:
