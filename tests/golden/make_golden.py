@@ -204,6 +204,7 @@ def main():
     print("wrote train_b4.npz: loss %.6f cls %.6f reg %.6f num_cls %d num_reg %d" % (
         tr["loss/loss"], tr["loss/cls_loss"], tr["loss/reg_loss"], tr["loss/num_cls"], tr["loss/num_reg"]))
     train_b32(ref, refdata, shapes, SEED)
+    lanercnn_fixture(SEED)
 
 
 def train_b32(ref, refdata, shapes, seed):
@@ -234,6 +235,103 @@ def train_b32(ref, refdata, shapes, seed):
     np.savez_compressed(os.path.join(HERE, "train_b32.npz"), **tr)
     print("wrote train_b32.npz: loss %.6f cls %.6f reg %.6f num_cls %d num_reg %d" % (
         tr["loss/loss"], tr["loss/cls_loss"], tr["loss/reg_loss"], tr["loss/num_cls"], tr["loss/num_reg"]))
+
+
+def lanercnn_fixture(seed):
+    """Row f4: the graph modules of the reference's fork model (lanercnn.py: LaneInput 280-351, LaneRoI 354-430,
+    LanePooling 433-514, GlobalGraphNet 517-600) run by the reference itself on small synthetic lane graphs."""
+    import types
+    import torch
+    from lanegcn_amd import data as gen
+    from golden_io import flatten
+    if "torchvision" not in sys.modules:
+        try:
+            import torchvision  # noqa: F401
+        except Exception:                                   # not installed here; lanercnn.py only imports it
+            sys.modules["torchvision"] = types.ModuleType("torchvision")
+    import lanercnn as rl
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(29)
+    scenes = [gen.synth_scene(rng, [4, 3], 6), gen.synth_scene(rng, [5], 4), gen.synth_scene(rng, [3, 3], 5)]
+    graphs = [s["graph"] for s in scenes]
+    import lanegcn as ref
+    import data as refdata
+    import copy
+    g = ref.graph_gather(ref.to_long(refdata.collate_fn(copy.deepcopy(scenes))["graph"]))
+    n = g["feats"].shape[0]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+
+    from oracle.lanercnn_oracle import seeded_state as seeded_rcnn
+    out = {"seed": np.int64(seed)}
+    flatten(scenes, "scenes/", out)
+    mods = {"roi": rl.LaneRoI(rl.config, 128), "ggn": rl.GlobalGraphNet(rl.config), "pool": rl.LanePooling(128, 128),
+            "input": rl.LaneInput(rl.config)}
+    names = {}
+    for i, (name, m) in enumerate(mods.items()):
+        shapes = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        m.eval().load_state_dict(seeded_rcnn(shapes, seed + i))      # weights are regenerated on the other side
+        names[name] = [[k, list(sh)] for k, sh in shapes]
+    with open(os.path.join(HERE, "lanercnn_state_names.json"), "w") as f:
+        json.dump(names, f)
+    with torch.no_grad():
+        x = t(rng.normal(0, 1, (n, 128)).astype(np.float32))
+        out["roi/x"] = x.numpy()
+        out["roi/out"] = mods["roi"](x.clone(), g).numpy().copy()
+        out["ggn/out"] = mods["ggn"](F_relu(x.clone()), g).numpy().copy()
+        # LaneInput: 8-d node features, 80-d agent features, agent -> node edges
+        n_agt = [5, 3, 4]
+        counts = np.cumsum([0] + [int(gr["num_nodes"]) for gr in graphs])
+        acount = np.cumsum([0] + n_agt)
+        li = {"feats": [t(rng.normal(0, 1, (int(gr["num_nodes"]), 8)).astype(np.float32)) for gr in graphs],
+              "agent_feat": [t(rng.normal(0, 1, (a, 80)).astype(np.float32)) for a in n_agt]}
+        u, v = [], []
+        for i, gr in enumerate(graphs):
+            m_e = 3 * int(gr["num_nodes"])
+            u.append(rng.integers(0, n_agt[i], m_e) + acount[i])
+            v.append(rng.integers(0, int(gr["num_nodes"]), m_e) + counts[i])
+        li["a2m"] = {"u": t(np.concatenate(u).astype(np.int64)), "v": t(np.concatenate(v).astype(np.int64))}
+        for i in range(3):
+            out["li/feats/%d" % i], out["li/agent_feat/%d" % i] = li["feats"][i].numpy(), li["agent_feat"][i].numpy()
+        out["li/a2m/u"], out["li/a2m/v"] = li["a2m"]["u"].numpy(), li["a2m"]["v"].numpy()
+        out["li/out"] = mods["input"](li).numpy().copy()
+        # LanePooling: context = every scene's lane graph, target = a subset of its nodes (scene 1 far away: no pairs)
+        ctx_g = {"ctrs": [t(gr["ctrs"].astype(np.float32)) for gr in graphs],
+                 "pose": [t(np.concatenate([gr["ctrs"], gr["feats"]], 1).astype(np.float32)) for gr in graphs]}
+        tgt_ctrs, tgt_pose = [], []
+        for i, gr in enumerate(graphs):
+            pick = rng.choice(int(gr["num_nodes"]), 20, replace=False)
+            c = gr["ctrs"][pick].astype(np.float32) + rng.normal(0, 1.0, (20, 2)).astype(np.float32)
+            if i == 1:
+                c = c + np.float32(500.0)
+            tgt_ctrs.append(t(c))
+            tgt_pose.append(t(np.concatenate([c, gr["feats"][pick].astype(np.float32)], 1)))
+        tgt_g = {"ctrs": tgt_ctrs, "pose": tgt_pose}
+        cfeat = F_relu(t(rng.normal(0, 1, (n, 128)).astype(np.float32)))
+        tfeat = F_relu(t(rng.normal(0, 1, (60, 128)).astype(np.float32)))
+        for i in range(3):
+            out["pool/tgt_ctrs/%d" % i], out["pool/tgt_pose/%d" % i] = tgt_ctrs[i].numpy(), tgt_pose[i].numpy()
+        out["pool/cfeat"], out["pool/tfeat"] = cfeat.numpy(), tfeat.numpy()
+        captured = []
+        real_index_add = torch.Tensor.index_add_
+
+        def spy(self, dim, index, source, *a, **k):
+            captured.append(index.numpy().copy())
+            return real_index_add(self, dim, index, source, *a, **k)
+
+        torch.Tensor.index_add_ = spy
+        try:
+            out["pool/out"] = mods["pool"](cfeat, ctx_g, tfeat.clone(), tgt_g, 6.0).numpy().copy()
+        finally:
+            torch.Tensor.index_add_ = real_index_add
+        assert len(captured) == 1
+        out["pool/wi"] = captured[0]
+    np.savez_compressed(os.path.join(HERE, "lanercnn_b3.npz"), **out)
+    print("wrote lanercnn_b3.npz: %d nodes, pooling pairs %d" % (n, len(out["pool/wi"])))
+
+
+def F_relu(x):
+    import torch
+    return torch.relu(x)
 
 
 B32_BATCH_SEED = 41
