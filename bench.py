@@ -206,7 +206,11 @@ def laneconv_launch_us(eng, fb, feat_map, feat_m2m, impl, reps=20):
         graph.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / (8 * reps)
+    launches = 1
+    if impl == "tiled":
+        lcp = ops.lc_plan(plan)               # the plan lane_conv used (cached on the CSR plan)
+        launches = 1 if len(lcp.gstart) == 2 else 2
+    return e0.elapsed_time(e1) * 1e3 / (8 * reps), launches
 
 
 def roofline_of(layer_us, n_nodes, sum_e, mma, workload, impl, launches):
@@ -251,16 +255,16 @@ def time_steps(step, steps, warmup, barrier, dev):
 
 def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup):
     """One arithmetic mode: S forwards in flight (the headline figure) and one forward at a time, both captured in
-    hipGraphs.  Several forwards in flight run LaneConv as ONE elastic launch per layer ("fused": it spreads over
-    whatever CUs the other streams leave free); a single forward runs the weight-stationary pair ("tiled": fewer
-    bytes per row through a CU, the faster one when it has the chip to itself).  DESIGN.md section 4."""
+    hipGraphs.  In the 16-bit-plane modes both run LaneConv on the weight-stationary kernel ("tiled"; at S2 its
+    "short" shape: 48-row blocks, one launch per layer); f32 and bf16x3 run the one-launch row-tile kernel
+    ("fused").  --laneconv forces either.  DESIGN.md sections 3.3 / 4."""
     from lanegcn_amd import data as gen
     from lanegcn_amd import dist as D
     from lanegcn_amd import ops
     from lanegcn_amd.engine import HotPathEngine, collate_flat
     ops.set_mma(mma)
     S = max(1, args.streams)
-    impl_multi = args.laneconv or ("fused" if S > 1 or mma in ("f32", "bf16x3") else "tiled")
+    impl_multi = args.laneconv or ("fused" if mma in ("f32", "bf16x3") else "tiled")
     impl_one = args.laneconv or ("fused" if mma in ("f32", "bf16x3") else "tiled")
     eng_multi = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"], lane_impl=impl_multi)
     eng_one = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"], lane_impl=impl_one)
@@ -410,7 +414,7 @@ def main():
         for _ in range(10):
             eng.forward(fb, actors, mapnet_only=args.mapnet_only)
     ksum = kt.summary()
-    lc_us, stages_tab, modes, extras = {}, None, {}, {}
+    lc_us, lc_launches, stages_tab, modes, extras = {}, {}, None, {}, {}
     n_scenes = len(scenes)
     if rank == 0:
         st = eng.forward(fb, actors, stages=not args.mapnet_only, mapnet_only=args.mapnet_only)
@@ -419,13 +423,13 @@ def main():
         f_map = st["nodes"] if args.mapnet_only else st["map_net"]
         f_m2m = st["nodes"] if args.mapnet_only else st["a2m"]
         for impl in (("fused",) if mma == "f32" else ("fused", "tiled")):
-            lc_us[impl] = laneconv_launch_us(eng, fb, f_map, f_m2m, impl)
+            lc_us[impl], lc_launches[impl] = laneconv_launch_us(eng, fb, f_map, f_m2m, impl)
         stages_tab = None if args.mapnet_only or world > 1 else stage_table(eng, fb, actors)
     if world == 1 and not args.mapnet_only and not args.no_graph:
         for m in [v for v in args.other_modes.split(",") if v and v != mma]:
             r, e_m = run_mode(args, m, mods, scenes, fb, actors, dev, rank, max(40, args.steps // 2), args.warmup)
             stm = e_m.forward(fb, actors, stages=True)
-            lcm = {impl: laneconv_launch_us(e_m, fb, stm["map_net"], stm["a2m"], impl)
+            lcm = {impl: laneconv_launch_us(e_m, fb, stm["map_net"], stm["a2m"], impl)[0]
                    for impl in (("fused",) if m == "f32" else ("fused", "tiled"))}
             dom = r["laneconv_impl"]["in_flight"]
             modes[m] = {
@@ -450,9 +454,10 @@ def main():
         workload_desc = ("%s: %s, %d scenes/GPU, %d lane nodes, %d edges, %d actors, random-init weights, inputs "
                          "resident in HBM, %s" % (args.workload, what, n_scenes, fb.n_nodes, sum_e, fb.n_actors, how))
         names = {"fused": ("lgcn::k_agg_mlp<1>" if mma == "f32" else "lgcn::k_agg_mlp_bf<RB,F,1>") + " (one-launch LaneConv layer)",
-                 "tiled": "lgcn::k_lc_tile<F,V> + lgcn::k_lc_combine<F> (weight-stationary LaneConv layer)"}
+                 "tiled": "lgcn::k_lc_tile<F,V,FIN>" + (" + lgcn::k_lc_combine<F>" if lc_launches.get("tiled", 1) > 1 else "") +
+                          " (weight-stationary LaneConv layer)"}
         dom = head["laneconv_impl"]["in_flight"]
-        roofline = roofline_of(lc_us[dom], fb.n_nodes, sum_e, mma, args.workload, dom, 1 if dom == "fused" else 2)
+        roofline = roofline_of(lc_us[dom], fb.n_nodes, sum_e, mma, args.workload, dom, lc_launches[dom])
         roofline["kernel"] = names[dom] + ", 8 layers/step: the LaneConv of the timed configuration"
         roofline["avg_launch_us_eager_event_pairs"] = float(np.mean(ksum["laneconv"])) * 1e3
         roofline["note"] = ("traffic = HBM bytes per layer from the PMC passes (profiles/pmc_traffic.json); it is below the "
@@ -472,7 +477,7 @@ def main():
             "config": {"workload": workload_desc,
                        "scenes_per_gpu": n_scenes, "parallelism": "dp%d (independent scene shards)" % args.gpus},
             "roofline": roofline,
-            "laneconv": {"impl": head["laneconv_impl"], "layer_us": lc_us,
+            "laneconv": {"impl": head["laneconv_impl"], "layer_us": lc_us, "launches_per_layer": lc_launches,
                          "roofline_by_impl": {k: {kk: roofline_of(v, fb.n_nodes, sum_e, mma, args.workload, k, 1)[kk]
                                                   for kk in ("bound", "achieved", "peak", "unit", "frac")}
                                               for k, v in lc_us.items()}},

@@ -39,6 +39,13 @@ template <> struct LcCfg<1, 0> { static constexpr int RBN = 6, CAP = 144, HRB = 
 template <> struct LcCfg<1, 1> { static constexpr int RBN = 12, CAP = 304, HRB = 6; };
 template <> struct LcCfg<2, 0> { static constexpr int RBN = 6, CAP = 144, HRB = 2; };     // bf16  : 256 B
 template <> struct LcCfg<2, 1> { static constexpr int RBN = 12, CAP = 304, HRB = 6; };
+// V = 2 "short": one workgroup per CU for a single small forward that finishes the layer in ONE launch (all 15 units,
+// n_groups = 1): half the rows of the shared shape, so that ~2 x as many CUs work, every source row of the 15 units in
+// one item, a second weight register set so that the next unit's 64 KB slice streams in under this unit's MFMAs
+// (with <= 48 rows the L2 -> CU weight stream, not the matrix pipe, is what a unit costs).
+template <> struct LcCfg<0, 2> { static constexpr int RBN = 2, CAP = 112, HRB = 2; };
+template <> struct LcCfg<1, 2> { static constexpr int RBN = 3, CAP = 176, HRB = 3; };
+template <> struct LcCfg<2, 2> { static constexpr int RBN = 3, CAP = 176, HRB = 3; };
 
 // Plan buffer (int32 words).  Item (b, u0) = row block b, units u0 .. u0 + n_span - 1; slot b * 15 + u0.
 //   hdr  [n_blocks*15][8] : n_live, n_src, n_span, 0, then 16 bytes: the live (non-empty) units of the item
@@ -200,6 +207,7 @@ struct LcTileParams {
     float eps;
     float *out;
     unsigned long long *stamps;       // diagnostic build (-DLGCN_STAMPS) only: [workgroup][2][64] s_memtime stamps
+    int exp;                          // diagnostic build only: 1 = do not fetch the next unit's weight slice (WRONG results)
 };
 
 // Source rows in LDS: row s at s * NP * 256 B, plane p at + p * 256 B, 16-byte slot q of the plane row at
@@ -223,17 +231,17 @@ template <int F>
 struct LcW { uint4 v[Fmt<F>::NP][2][2]; };     // [plane][K-step of this wave's half][16-channel block]
 
 // LDS geometry of one (format, row-block height) instance.  Main loop: (CAP + 1) source rows.  Epilogue, per
-// phase of HR rows: the two K halves' fp32 tiles T0 | T1, then (finishing launches) the Y operand planes at LDS
-// rows YR0 .. YR0 + HR (YR0 a multiple of 16 so that the read swizzle of a Y row is its row number's).
+// phase of HR rows: (finishing launches) the Y operand planes at LDS rows 0 .. HR, then the two K halves' fp32 tiles
+// T0 | T1 at byte TOFF.
 template <int F, int V>
 struct LcGeom {
     static constexpr int RBN = LcCfg<F, V>::RBN, M = 16 * RBN, NP = Fmt<F>::NP, ROWB = NP * 256, CAP = LcCfg<F, V>::CAP;
     static constexpr int HRB = LcCfg<F, V>::HRB, HR = 16 * HRB, PH = RBN / HRB;
     static constexpr int T2_BYTES = 2 * HR * kLDA * 4;
-    static constexpr int YR0 = (((T2_BYTES + ROWB - 1) / ROWB + 15) / 16) * 16;
-    static constexpr int EP_BYTES = (YR0 + HR) * ROWB, SRC_BYTES = (CAP + 1) * ROWB;
+    static constexpr int YR0 = 0, TOFF = HR * ROWB;
+    static constexpr int EP_BYTES = TOFF + T2_BYTES, SRC_BYTES = (CAP + 1) * ROWB;
     static constexpr int SMEM = SRC_BYTES > EP_BYTES ? SRC_BYTES : EP_BYTES;
-    static_assert(RBN % HRB == 0 && SMEM <= (V == 0 ? 78 : 160) * 1024 - 256, "row block does not fit the LDS");
+    static_assert(RBN % HRB == 0 && SMEM <= (V == 0 ? 78 : V == 1 ? 160 : 96) * 1024 - 256, "row block does not fit the LDS");
 };
 
 template <int F, int V, bool FIN>
@@ -242,10 +250,12 @@ void k_lc_tile(const LcTileParams p) {
     using G = LcGeom<F, V>;
     constexpr int RBN = G::RBN, CAP = G::CAP, NP = G::NP, ROWB = G::ROWB, M = G::M, HRB = G::HRB, HR = G::HR, PH = G::PH;
     constexpr int NIT = (CAP + 15) / 16;
-    constexpr bool DBUF = V == 1;                      // tall: a second weight-slice register set (256 VGPRs to spend)
+    constexpr bool DBUF = V >= 1;                      // tall / short: a second weight-slice register set (256 VGPRs to spend)
     constexpr int NLC = RBN > 8 ? 2 : 1;               // uint4 words of the per-row index
+    constexpr bool PIPE = V == 2;                      // short: A fragments requested NB - 1 sub-blocks ahead
+    constexpr int NB = RBN % 2 == 0 ? 2 : 3, PD = NB - 1;
+    static_assert(!PIPE || (RBN % NB == 0 && RBN >= PD && RBN <= 8), "pipelined unit loop: buffer index must be static");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
-    __shared__ int s_ul[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cq = wave & 3, kh = wave >> 2;          // channel quarter, half of K
     const int kq = lane >> 4;
@@ -274,12 +284,16 @@ void k_lc_tile(const LcTileParams p) {
     LcW<F> wc, wn;                                     // wn is used by the tall shape only
     uint4 lc[NLC], ln[NLC];
     auto load_w_ks = [&](const float *wp, LcW<F> &w, int ks) {     // K-step ks of this wave's weight slice
-        const uint4 *Wp = reinterpret_cast<const uint4 *>(wp);
+        // explicitly a GLOBAL pointer: behind the scalar-register pin below the compiler no longer infers the address
+        // space, and a flat load would count on lgkmcnt too (every wait for it would drain the LDS reads in flight)
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        typedef const u32x4_t __attribute__((address_space(1))) *gptr_t;
+        gptr_t Wp = (gptr_t)(uintptr_t)wp;
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-                w.v[pl][ks][cb] = Wp[((((pl * 4 + cq) * 4 + (2 * kh + ks)) * 2 + cb) << 6) + lane];
+                w.v[pl][ks][cb] = __builtin_bit_cast(uint4, u32x4_t(Wp[((((pl * 4 + cq) * 4 + (2 * kh + ks)) * 2 + cb) << 6) + lane]));
     };
     auto load_loc = [&](int uu, uint4 (&lo)[NLC]) {
         const uint4 *lp = locp + (((int64_t)b * kLcUnits + uu) * 256 * 2) / 16 + (lane & 15) * 2;
@@ -294,21 +308,46 @@ void k_lc_tile(const LcTileParams p) {
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) a[pl] = *reinterpret_cast<const uint4 *>(q + pl * 256);
     };
-    auto mm = [&](f32x4 (&c2)[2], int ks, const uint4 (&a)[NP]) {
+    // The weight slice is the FIRST matrix operand and the rows the second (D^T = W^T X^T; the two operands have the
+    // same register layout): a lane then holds 4 CONSECUTIVE channels of row (lane & 15), so the accumulators go to
+    // the fp32 tiles as 16-byte stores.
+    auto mmw = [&](f32x4 (&c2)[2], int ks, const uint4 (&a)[NP], const LcW<F> &w) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             f32x4 c = c2[cb];
 #pragma unroll
             for (int q = 0; q < Fmt<F>::NPROD; ++q)      // smallest terms first
-                c = Fmt<F>::mfma(a[Fmt<F>::PA[q]], wc.v[Fmt<F>::PB[q]][ks][cb], c);
+                c = Fmt<F>::mfma(w.v[Fmt<F>::PB[q]][ks][cb], a[Fmt<F>::PA[q]], c);
             c2[cb] = c;
         }
     };
+    auto mm = [&](f32x4 (&c2)[2], int ks, const uint4 (&a)[NP]) { mmw(c2, ks, a, wc); };
 
+    // the 15 weight pointers are pinned in scalar registers (the empty asm keeps the compiler from re-reading them
+    // from the argument segment -- an s_load plus an lgkmcnt(0) wait, which also drains the LDS reads in flight)
+    const float *wreg[kLcUnits];
+#pragma unroll
+    for (int u = 0; u < kLcUnits; ++u) {
+        wreg[u] = p.wp[u];
+        asm volatile("" : "+s"(wreg[u]));
+    }
     for (int u0 = p.gstart[g]; u0 < uend;) {
         const int64_t item = (int64_t)b * kLcUnits + u0;
         const int4 h = *reinterpret_cast<const int4 *>(hdr + item * kLcHdr);
         const int4 hu = *reinterpret_cast<const int4 *>(hdr + item * kLcHdr + 4);
+        // the item's source list does not depend on the header's contents: both are requested together
+        int2 e[NIT];
+        {
+            int opq = 0;
+            asm volatile("" : "+v"(opq));
+            const int hw = (tid >> 5) + opq;
+            const int2 *sl = srcp + item * p.cap;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {      // unconditional loads (index clamped): one round trip for all
+                const int s = it * 16 + hw;
+                e[it] = sl[s < p.cap ? s : p.cap - 1];
+            }
+        }
         const int n_live = __builtin_amdgcn_readfirstlane(h.x), n_src = __builtin_amdgcn_readfirstlane(h.y);
         const int span = __builtin_amdgcn_readfirstlane(h.z) > 0 ? __builtin_amdgcn_readfirstlane(h.z) : 1;
         if (n_live <= 0) { u0 += span; continue; }
@@ -317,11 +356,28 @@ void k_lc_tile(const LcTileParams p) {
         // ---- the item's source rows -> LDS planes (one half-wave per row, the row loads of a batch in flight
         // together); the first unit's weight slice + row index are requested before them and used after them
         LC_STAMP();   // header in
-        const int uf = __builtin_amdgcn_readfirstlane(hu.x & 0xff);
+        // the item's live units (16 bytes of the header) stay in scalar registers, and a unit's weight pointer is
+        // SELECTED from the launch arguments: a unit boundary costs no LDS or scalar-memory round trip
+        const unsigned long long ulo = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(hu.x) |
+                                       ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(hu.y) << 32);
+        const unsigned long long uhi = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(hu.z) |
+                                       ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(hu.w) << 32);
+        auto unit_at = [&](int k) -> int { return (int)(((k < 8 ? ulo : uhi) >> (8 * (k & 7))) & 0xffull); };
+        auto wptr = [&](int un) -> const float * {
+            const float *r = wreg[0];
+#pragma unroll
+            for (int u = 1; u < kLcUnits; ++u) {
+                r = un == u ? wreg[u] : r;
+                asm volatile("" : "+s"(r));      // keeps the chain a chain of s_cselect (not an indexed table in memory)
+            }
+            return r;
+        };
+        const int uf = unit_at(0);
         if (DBUF) {       // tall shape: registers to spare, the slice arrives under the loader
-            load_w_ks(p.wp[uf], wc, 0);
-            load_w_ks(p.wp[uf], wc, 1);
+            load_w_ks(wptr(uf), wc, 0);
+            load_w_ks(wptr(uf), wc, 1);
             load_loc(uf, lc);
+            if (PIPE && n_live > 1) load_loc(unit_at(1), ln);
         }
         // the zero row and (below) the unit list are written by EVERY thread, redundantly, rather than by the first
         // few lanes of wave 0: with partial-exec regions in this prologue the register allocator's spill reloads
@@ -333,17 +389,10 @@ void k_lc_tile(const LcTileParams p) {
             int opq = 0;
             asm volatile("" : "+v"(opq));
             const int hw = (tid >> 5) + opq, l = (tid & 31) + opq;
-            const int2 *sl = srcp + item * p.cap;
-            int2 e[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; ++it) {      // unconditional loads (index clamped): one round trip for all
-                const int s = it * 16 + hw;
-                e[it] = sl[s < p.cap ? s : p.cap - 1];
-            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (it * 16 + hw >= n_src) e[it] = make_int2(0, -1);   // y < 0: no row
-            constexpr int NH = DBUF ? (NIT + 1) / 2 : (NIT + 1) / 2 < 5 ? (NIT + 1) / 2 : 5;   // row loads in flight per lane (registers)
+            constexpr int NH = V == 2 ? NIT : DBUF ? (NIT + 1) / 2 : (NIT + 1) / 2 < 5 ? (NIT + 1) / 2 : 5;   // row loads in flight per lane (registers)
 #pragma unroll
             for (int h0 = 0; h0 < NIT; h0 += NH) {
                 f32x4 v[NH];
@@ -367,14 +416,9 @@ void k_lc_tile(const LcTileParams p) {
                     if (h0 + j < NIT && e[h0 + j].y >= 0) lc_split_store<F>(smem, (h0 + j) * 16 + hw, l, v[j]);
             }
         }
-        {
-            const int t16 = tid & 15;
-            const int w = (t16 >> 2) == 0 ? hu.x : (t16 >> 2) == 1 ? hu.y : (t16 >> 2) == 2 ? hu.z : hu.w;
-            s_ul[t16] = (w >> (8 * (t16 & 3))) & 0xff;
-        }
         if (!DBUF) {      // shared shape: requested behind the row loads; arrives under the barrier / the other workgroup
-            load_w_ks(p.wp[uf], wc, 0);
-            load_w_ks(p.wp[uf], wc, 1);
+            load_w_ks(wptr(uf), wc, 0);
+            load_w_ks(wptr(uf), wc, 1);
             load_loc(uf, lc);
         }
         LC_STAMP();   // own source rows stored
@@ -386,11 +430,78 @@ void k_lc_tile(const LcTileParams p) {
         // behind the last unit of a finishing launch): tall shape -- fetched into a second register set while
         // this unit's MFMAs run; shared shape -- each K-step's registers are refilled as soon as the last
         // sub-block has used them (the co-resident workgroup covers what latency that leaves).
+        if constexpr (PIPE) {
+            // short shape.  The A fragments of a sub-block are requested PD sub-blocks ahead, across unit boundaries.
+            // The vector-issue port is what this loop is short of (an MFMA holds it for 8 of its 16 cycles, every
+            // other vector instruction for 4+), so a unit boundary moves no registers: units alternate between two
+            // weight sets and two row-index sets (the loop is unrolled by two), and the next unit's weight slice is
+            // requested in two halves between the MFMA groups.
+            uint4 A[NB][2][NP];
+            auto row_in = [&](const uint4 (&lo)[NLC], int rb) -> uint32_t {
+                const uint32_t w = rb < 2 ? lo[0].x : rb < 4 ? lo[0].y : rb < 6 ? lo[0].z : lo[0].w;
+                const uint32_t w16 = (w >> (16 * (rb & 1))) & 0xffffu;
+                return w16 == 0xffffu ? (uint32_t)CAP : w16;
+            };
+#pragma unroll
+            for (int d = 0; d < PD; ++d) {
+                rd(row_in(lc, d), 0, A[d][0]);
+                rd(row_in(lc, d), 1, A[d][1]);
+            }
+            auto unit = [&](int k, LcW<F> &wcur, LcW<F> &wnxt, uint4 (&lcur)[NLC], uint4 (&lnxt)[NLC]) {
+                // every request of a unit is unconditional (behind the last unit they fetch the second weight / re-read
+                // valid rows to no effect): with no branch in the loop the wait counters are exact
+                const float *wnext = k + 1 < n_live ? wptr(unit_at(k + 1)) : p.wp2;
+#pragma unroll
+                for (int rb = 0; rb < RBN; ++rb) {
+                    const int t = rb + PD;
+                    __builtin_amdgcn_sched_barrier(0);
+#ifdef LGCN_STAMPS
+                    if (!(p.exp & 1))
+#endif
+                    if (rb < 2) load_w_ks(wnext, wnxt, rb);
+#ifdef LGCN_STAMPS
+                    if (!(p.exp & 2)) {
+#endif
+                    if (t < RBN) {
+                        rd(row_in(lcur, t), 0, A[t % NB][0]);
+                        rd(row_in(lcur, t), 1, A[t % NB][1]);
+                    } else {
+                        rd(row_in(lnxt, t - RBN), 0, A[t % NB][0]);
+                        rd(row_in(lnxt, t - RBN), 1, A[t % NB][1]);
+                    }
+#ifdef LGCN_STAMPS
+                    }
+#endif
+                    // this unit's row index is dead behind its last own-row request: the index of the unit after
+                    // the next one lands there (needed one unit from now)
+                    if (rb == (RBN - PD > 0 ? RBN - PD - 1 : 0)) load_loc(unit_at(k + 2 < n_live ? k + 2 : n_live - 1), lcur);
+#ifdef LGCN_STAMPS
+                    if (p.exp & 4) continue;
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    mmw(acc[rb], 0, A[rb % NB][0], wcur);
+                    mmw(acc[rb], 1, A[rb % NB][1], wcur);
+#ifdef LGCN_STAMPS
+                    if ((p.exp & 16) && k < 6) LC_STAMP();
+#endif
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                LC_STAMP();   // unit k done
+            };
+            for (int k = 0; k < n_live; k += 2) {
+                unit(k, wc, wn, lc, ln);
+                if (k + 1 < n_live) unit(k + 1, wn, wc, ln, lc);
+            }
+            if (n_live & 1) wc = wn;      // the second weight (ctr2) is used from wc
+        } else
         for (int k = 0; k < n_live; ++k) {
             const bool more = k + 1 < n_live, tail2 = !more && last_item && finish;
-            const int un = more ? __builtin_amdgcn_readfirstlane(s_ul[k + 1]) : 0;
-            const float *wnext = more ? p.wp[un] : p.wp2;
+            const int un = more ? unit_at(k + 1) : 0;
+            const float *wnext = more ? wptr(un) : p.wp2;
             if (DBUF) {
+#ifdef LGCN_STAMPS
+                if (p.exp & 1) wn = wc; else
+#endif
                 if (more || tail2) { load_w_ks(wnext, wn, 0); load_w_ks(wnext, wn, 1); }
                 if (more) load_loc(un, ln);
             }
@@ -436,18 +547,16 @@ void k_lc_tile(const LcTileParams p) {
     // ---- epilogue, HR rows at a time: each K half stores its accumulators into its own fp32 tile, the row threads
     // add the two tiles on the way out (8 threads per row, 512-B coalesced rows).  A finishing launch goes on:
     // GN -> ReLU -> operand planes -> ctr2 on the matrix cores (same K split) -> GN -> + X -> ReLU -> out.
-    float *T0 = reinterpret_cast<float *>(smem);
+    float *T0 = reinterpret_cast<float *>(smem + G::TOFF);
     float *Tk = T0 + kh * (HR * kLDA);
     constexpr int SW = (HR + 63) / 64;              // sweeps of 64 rows
     auto tiles_from_acc = [&](int ph) {
 #pragma unroll
         for (int rb = 0; rb < HRB; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                float *q = Tk + (16 * rb + 4 * (lane >> 4)) * kLDA + 32 * cq + 16 * cb + (lane & 15);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) q[i * kLDA] = acc[ph * HRB + rb][cb][i];
-            }
+            for (int cb = 0; cb < 2; ++cb)
+                *reinterpret_cast<f32x4 *>(Tk + (16 * rb + (lane & 15)) * kLDA + 32 * cq + 16 * cb + 4 * (lane >> 4)) =
+                    acc[ph * HRB + rb][cb];
     };
     auto tile_row = [&](int sweep) {
         RowVals r = row_load(T0 + sweep * 64 * kLDA, tid);
@@ -555,7 +664,6 @@ __global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile = xcd_chunk_remap(blockIdx.x, n_tiles);
     const int64_t row0 = (int64_t)tile * 32;
-    const int b = (int)(row0 / p.M), rib0 = (int)(row0 % p.M);
     const uint4 *wp2 = reinterpret_cast<const uint4 *>(p.wp2);
 
     const int row = tid >> 3;
@@ -570,14 +678,15 @@ __global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_
     RowVals r;
 #pragma unroll
     for (int j = 0; j < 4; ++j) r.v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t prow = (int64_t)(live_row ? rib0 + row : rib0);
+    const int64_t nl = live_row ? n : row0;       // a 32-row tile may straddle row blocks (M = 48): per-row block index
+    const int64_t b = nl / p.M, prow = nl % p.M;
     const int cnt = p.n_groups;
     for (int j0 = 0; j0 < cnt; j0 += 4) {       // four partial rows in flight; added in group order
         RowVals x[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int id = j0 + q < cnt ? j0 + q : cnt - 1;
-            const float *pp = p.part + (((int64_t)b * cnt + id) * p.M + prow) * kC + 4 * (tid & 7);
+            const float *pp = p.part + ((b * cnt + id) * p.M + prow) * kC + 4 * (tid & 7);
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[q].v[j] = *reinterpret_cast<const float4 *>(pp + 32 * j);
         }
@@ -612,8 +721,8 @@ __global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_
 static int fmt_of(int mma) { return mma == LGCN_MMA_BF16X3 ? 0 : mma == LGCN_MMA_F16X2 ? 1 : 2; }
 
 static bool lc_cfg(int mma, int variant, int *M, int *cap) {
-    if (variant < 0 || variant > 1) return false;
-#define LGCN_CFG(F_) do { if (variant) { *M = 16 * LcCfg<F_, 1>::RBN; *cap = LcCfg<F_, 1>::CAP; } else { *M = 16 * LcCfg<F_, 0>::RBN; *cap = LcCfg<F_, 0>::CAP; } } while (0)
+    if (variant < 0 || variant > 2) return false;
+#define LGCN_CFG(F_) do { if (variant == 2) { *M = 16 * LcCfg<F_, 2>::RBN; *cap = LcCfg<F_, 2>::CAP; } else if (variant) { *M = 16 * LcCfg<F_, 1>::RBN; *cap = LcCfg<F_, 1>::CAP; } else { *M = 16 * LcCfg<F_, 0>::RBN; *cap = LcCfg<F_, 0>::CAP; } } while (0)
     switch (fmt_of(mma)) {
         case 0: LGCN_CFG(0); break;
         case 1: LGCN_CFG(1); break;
@@ -647,7 +756,7 @@ int lgcn_lc_config(int mma, int variant, int32_t *rows_per_block, int32_t *cap) 
 }
 
 static bool lc_geom_ok(int64_t n_nodes, int M, int cap) {
-    return n_nodes >= 0 && n_nodes <= 0x7fffffff && (M == 64 || M == 96 || M == 128 || M == 192) && cap >= M &&
+    return n_nodes >= 0 && n_nodes <= 0x7fffffff && (M == 32 || M == 48 || M == 64 || M == 96 || M == 128 || M == 192) && cap >= M &&
            cap <= kLcHash / 2;
 }
 
@@ -692,11 +801,14 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
     LGCN_CHECK_PTR(ph);
     const lgcn_laneconv_t &q = *ph;
     if (!lc_mma_ok(q.mma)) return LGCN_ESHAPE;
-    int Ms, Ml, caps, capl;
-    lc_cfg(q.mma, 0, &Ms, &caps);
-    lc_cfg(q.mma, 1, &Ml, &capl);
     const int M = q.rows_per_block;
-    if (q.n_rows < 0 || (M != Ms && M != Ml) || q.cap < M || q.cap > (M == Ml ? capl : caps) || q.n_rows > 0x7fffffff) return LGCN_EINVAL;
+    int variant = -1, capv = 0;
+    for (int v = 0; v < 3; ++v) {
+        int Mv, cv;
+        lc_cfg(q.mma, v, &Mv, &cv);
+        if (Mv == M) { variant = v; capv = cv; }
+    }
+    if (q.n_rows < 0 || variant < 0 || q.cap < M || q.cap > capv || q.n_rows > 0x7fffffff) return LGCN_EINVAL;
     if (!lc_groups_ok(q.n_units, q.n_groups, q.gstart)) return LGCN_EINVAL;
     if (q.n_rows == 0) return LGCN_OK;
     const void *ptrs[] = {q.x, q.plan, q.out, q.wp2, q.gn1_g, q.gn1_b, q.gn2_g, q.gn2_b};
@@ -717,21 +829,25 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
     t.part = q.part;
     t.wp2 = q.wp2; t.gn1_g = q.gn1_g; t.gn1_b = q.gn1_b; t.gn2_g = q.gn2_g; t.gn2_b = q.gn2_b; t.eps = q.eps; t.out = q.out;
     t.stamps = nullptr;
+    t.exp = 0;
 #ifdef LGCN_STAMPS
     t.stamps = g_lc_stamps;
+    { const char *e = getenv("LGCN_EXP_LC"); t.exp = e ? atoi(e) : 0; }
 #endif
     LcCombParams c{q.part, q.n_rows, M, q.n_groups, q.x, q.wp2, q.gn1_g, q.gn1_b, q.gn2_g, q.gn2_b, q.eps, q.out};
     const unsigned grid1 = (unsigned)(n_blocks * q.n_groups);
     const int n_tiles = (int)((q.n_rows + 31) / 32);
-    const bool tall = M == Ml;
+#define LGCN_LCV(F_, FIN_)                                                                                   \
+    do {                                                                                                     \
+        if (variant == 2) hipLaunchKernelGGL((k_lc_tile<F_, 2, FIN_>), dim3(grid1), dim3(512), 0, st, t);     \
+        else if (variant == 1) hipLaunchKernelGGL((k_lc_tile<F_, 1, FIN_>), dim3(grid1), dim3(512), 0, st, t); \
+        else hipLaunchKernelGGL((k_lc_tile<F_, 0, FIN_>), dim3(grid1), dim3(512), 0, st, t);                  \
+    } while (0)
 #define LGCN_LC(F_)                                                                                          \
     do {                                                                                                     \
-        if (q.n_groups == 1) {                                                                               \
-            if (tall) hipLaunchKernelGGL((k_lc_tile<F_, 1, true>), dim3(grid1), dim3(512), 0, st, t);         \
-            else hipLaunchKernelGGL((k_lc_tile<F_, 0, true>), dim3(grid1), dim3(512), 0, st, t);              \
-        } else {                                                                                             \
-            if (tall) hipLaunchKernelGGL((k_lc_tile<F_, 1, false>), dim3(grid1), dim3(512), 0, st, t);        \
-            else hipLaunchKernelGGL((k_lc_tile<F_, 0, false>), dim3(grid1), dim3(512), 0, st, t);             \
+        if (q.n_groups == 1) LGCN_LCV(F_, true);                                                             \
+        else {                                                                                               \
+            LGCN_LCV(F_, false);                                                                             \
             hipLaunchKernelGGL((k_lc_combine<F_>), dim3(n_tiles), dim3(256), 0, st, c, n_tiles);             \
         }                                                                                                    \
     } while (0)
@@ -741,6 +857,7 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
         default: LGCN_LC(2); break;
     }
 #undef LGCN_LC
+#undef LGCN_LCV
     return launch_status();
 }
 

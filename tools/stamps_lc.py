@@ -44,7 +44,10 @@ def main():
         for _ in range(3):
             ops.laneconv_fwd(x, lcp, wps, M._gn(fuse["norm"][0]), ops.packed(c2.linear.weight), M._gn(c2.norm), part=part)
         torch.cuda.synchronize()
-    st = stamps.cpu().numpy().reshape(n_wg, 2, 64).astype(np.float64)
+    raw = stamps.cpu().numpy().reshape(n_wg, 2, 64)
+    rt = raw[:, 0, 63] - raw[:, 0, 62]                    # 100 MHz reference clock over the workgroup
+    cy = raw[:, 0, 61] - raw[:, 0, 0]
+    st = raw[:, :, :60].astype(np.float64)                # slots 61..63: end stamp + the reference clock pair
     units = [lcp.gstart[i + 1] - lcp.gstart[i] for i in range(len(lcp.gstart) - 1)]
     print("groups=%d (units per group %s) mma=%s workgroups=%d" % (groups, units, ops.get_mma(), n_wg))
     g = np.arange(n_wg) % len(units)      # not exact under the XCD remap; use the longest common prefix
@@ -55,6 +58,11 @@ def main():
         med = lambda a: float(np.median(a))
         names = ["start->header", "header->rows stored", "barrier"] + ["unit %d" % k for k in range(nu)]
         print(" %s:" % name, " | ".join("%s %.0f" % (n, med(d[:, i])) for i, n in enumerate(names)))
+    if os.environ.get("LGCN_STAMPS_RAW"):      # every delta, in stamp order (for the LGCN_EXP_LC diagnostic knobs)
+        for role, name in ((0, "wave 0"), (1, "wave 7")):
+            d = np.diff(st[:, role, :], axis=1)
+            cnt = int(np.median((st[:, role, :] > 0).sum(1)))
+            print(" %s raw:" % name, " ".join("%.0f" % float(np.median(d[:, i])) for i in range(cnt - 1)))
     # tail stamps are counted from the end of each workgroup's record
     for role, name in ((0, "wave 0"), (1, "wave 7")):
         s = st[:, role, :]
@@ -64,6 +72,7 @@ def main():
         print(" %s tail: last barrier %.0f | accumulators -> tiles %.0f | rest of the epilogue %.0f ; whole workgroup %.0f" % (
             name, np.median(dd[:, 2]), np.median(dd[:, 1]), np.median(dd[:, 0]), np.median(tail[:, 0] - s[:, 0])))
     start, end = st[:, 0, 0], st[np.arange(n_wg), 0, (st[:, 0, :] > 0).sum(1) - 1]
+    print(" shader clock %.2f GHz (cycles / reference time, median over workgroups)" % float(np.median(cy / np.maximum(rt, 1)) * 0.1))
     print(" first start -> last start %.0f ; first start -> last end %.0f cycles" % (start.max() - start.min(), end.max() - start.min()))
 
 
