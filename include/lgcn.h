@@ -120,6 +120,33 @@ typedef struct {
 } lgcn_pairs_job_t;
 int lgcn_pairs_build_multi(const lgcn_pairs_job_t *jobs, int n_jobs, void *stream);
 
+/*
+ * The whole integer stage of a forward in THREE launches (count | scan | fill) instead of the twelve of
+ * lgcn_graph_gather + lgcn_csr_build + lgcn_pairs_build_multi; bit-identical outputs.
+ *   idx_local [n_elem], seg_off / seg_base [n_seg]: as lgcn_graph_gather (reference lanegcn.py:191-208); relation r's
+ *     destination indices are elements u_off[r] .. u_off[r] + n_edges[r] of the gathered array, its sources start at
+ *     v_off[r] (the global indices are formed on the fly and not written out).
+ *   rowptr [lgcn_csr_rowptr_elems], col [sum n_edges]: the plan of lgcn_csr_build.
+ *   cnt   : lgcn_csr_rowptr_elems(n_nodes, n_rel) 64-bit words, 8-byte aligned.  MUST BE ALL ZERO on entry; the
+ *           launches leave it all zero again, so one buffer per stream serves every call without a zeroing launch.
+ *   uv    : int32 workspace, lgcn_index_uv_elems(sum n_edges) elements.
+ *   jobs  : up to four pair searches (HOST array, as lgcn_pairs_build_multi); n_jobs may be 0.
+ * Limits of this entry point (LGCN_ESHAPE beyond them; use the separate calls there): sum n_edges < 2^21,
+ * lgcn_csr_rowptr_elems <= 2^22.
+ */
+typedef struct {
+    const int64_t *idx_local; int64_t n_elem;
+    const int64_t *seg_off, *seg_base; int32_t n_seg, n_rel;
+    int64_t u_off[LGCN_MAX_REL], v_off[LGCN_MAX_REL], n_edges[LGCN_MAX_REL];
+    int64_t n_nodes;
+    int32_t *rowptr, *col;
+    void *cnt;
+    int32_t *uv;
+    const lgcn_pairs_job_t *jobs; int32_t n_jobs, pad_;
+} lgcn_index_t;
+int64_t lgcn_index_uv_elems(int64_t n_edges);
+int lgcn_index_build(const lgcn_index_t *p_host, void *stream);
+
 /* int32 -> int64 widening of the first *n (device count, clamped to cap)
  * entries; the tail is left untouched.  Used to hand hi/wi back as the
  * reference's LongTensors. */
@@ -188,7 +215,10 @@ typedef struct {
 enum {
     LGCN_REL_IDENT = 0,      /* A[n] = src[n]                              */
     LGCN_REL_CSR = 1,        /* A[n] = sum_{e in row key(n,ridx)} src[col[e]] */
-    LGCN_REL_RANGE = 2       /* A[n] = sum_{p in [rowptr[n],rowptr[n+1])} src[p] */
+    LGCN_REL_RANGE = 2,      /* A[n] = sum_{p in [rowptr[n],rowptr[n+1])} src[p] */
+    LGCN_REL_RANGE16 = 3     /* as RANGE over a src written by lgcn_att_pairs_ws(seg = 16): of a segment [b, e) only
+                                rows b and the multiples of 16 inside (b, e) hold data (sums of 16-aligned pieces);
+                                split-precision modes only (F32: LGCN_ESHAPE) */
 };
 
 enum {                        /* lgcn_agg_mlp flags                         */
@@ -320,6 +350,25 @@ int lgcn_att_pairs(const float *agt_ctrs, const float *ctx_ctrs,
                    const float *wpc0e, const float *U, const float *V,
                    const float *gc, const float *btc,
                    float eps, int mma, float *m, void *stream);
+
+/*
+ * lgcn_att_pairs with both 128 x 128 weights held in registers by persistent workgroups (64-pair tiles): the same
+ * m_p, without the 128 KB of weight fragments that lgcn_att_pairs streams through the CU per 32-pair tile.
+ * Split-precision modes only (F32: LGCN_ESHAPE).
+ *   seg = 0 : m[p] = m_p for every pair p < *n_pairs (as lgcn_att_pairs).
+ *   seg = 16: hi must be sorted (lgcn_pairs_build output).  Within every 16-aligned group of pair rows the rows of
+ *             one target are summed in pair order; the sum is written at the row of the piece's first pair and the
+ *             other rows of m are left untouched.  Pass m to lgcn_agg_mlp as an LGCN_REL_RANGE16 relation: for few
+ *             targets with many pairs each (M2A, A2A) the tail then reads ~1/12 of the rows.
+ */
+int lgcn_att_pairs_ws(const float *agt_ctrs, const float *ctx_ctrs,
+                      const int32_t *hi, const int32_t *wi,
+                      const int32_t *n_pairs, int64_t cap,
+                      const float *wd0, const float *bd0, const float *wpd2,
+                      const float *gd, const float *btd,
+                      const float *wpc0e, const float *U, const float *V,
+                      const float *gc, const float *btc,
+                      float eps, int mma, int seg, float *m, void *stream);
 
 /*
  * Att.forward for given pairs in ONE launch per tile of target rows (lanegcn.py:691-709): query path, per-pair MLP,

@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblgcn.so")
 
 MAX_REL = 16
-REL_IDENT, REL_CSR, REL_RANGE = 0, 1, 2
+REL_IDENT, REL_CSR, REL_RANGE, REL_RANGE16 = 0, 1, 2, 3
 F_GN1, F_RELU1, F_GEMM2, F_GN2, F_RES, F_RELU2 = 1, 2, 4, 8, 16, 32
 MMA_F32, MMA_BF16X3, MMA_BF16, MMA_F16X2 = 0, 1, 2, 3
 MMA_NAMES = {"f32": MMA_F32, "bf16x3": MMA_BF16X3, "bf16": MMA_BF16, "f16x2": MMA_F16X2}
@@ -27,6 +27,17 @@ class PairsJob(C.Structure):      # lgcn_pairs_job_t
         ("dist_th", C.c_float), ("pad_", C.c_int32),
         ("hi", C.c_void_p), ("wi", C.c_void_p), ("cap", C.c_int64),
         ("n_pairs", C.c_void_p), ("rowptr", C.c_void_p), ("ws", C.c_void_p),
+    ]
+
+
+class Index(C.Structure):         # lgcn_index_t
+    _fields_ = [
+        ("idx_local", C.c_void_p), ("n_elem", C.c_int64),
+        ("seg_off", C.c_void_p), ("seg_base", C.c_void_p), ("n_seg", C.c_int32), ("n_rel", C.c_int32),
+        ("u_off", C.c_int64 * MAX_REL), ("v_off", C.c_int64 * MAX_REL), ("n_edges", C.c_int64 * MAX_REL),
+        ("n_nodes", C.c_int64),
+        ("rowptr", C.c_void_p), ("col", C.c_void_p), ("cnt", C.c_void_p), ("uv", C.c_void_p),
+        ("jobs", C.c_void_p), ("n_jobs", C.c_int32), ("pad_", C.c_int32),
     ]
 
 
@@ -103,6 +114,9 @@ SIGNATURES = {
     "lgcn_check_finite": (C.c_int, [_P, _L, _P, _L, _P, _I, _P]),
     "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
     "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
+    "lgcn_index_uv_elems": (C.c_int64, [_L]),
+    "lgcn_index_build": (C.c_int, [_P, _P]),
+    "lgcn_att_pairs_ws": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _I, _P, _P]),
 }
 
 _lib = None

@@ -186,6 +186,205 @@ __global__ __launch_bounds__(256) void k_att_fused(const AttFusedParams p) {
     }
 }
 
+
+// --------------------------------------------------- weight-stationary pair MLP -----
+// lgcn_att_pairs_ws: the per-pair MLP of Att.forward (lanegcn.py:691-700) with both 128 x 128 weights held in
+// REGISTERS for the whole launch.  k_att_pairs_bf streams 128 KB of weight fragments L2 -> VGPR per 32-pair tile
+// (32 vector-memory instructions per wave and tile, each ~60-100 cycles of issue): at S2 that stream, not the
+// matrix cores, is what its 12-33 us are.  Here a persistent workgroup of 8 waves takes 64-pair tiles; wave w owns
+// output channels 16 w .. 16 w + 15 of BOTH GEMMs (its slice of W_d2 and W_c0e: 2 x 8 KB = 64 VGPRs in f16x2), the A
+// operand planes and the fp32 tile live in LDS (<= 80 KB: two workgroups per CU cover each other's row phases), the
+// small per-channel parameters (W_d0, b_d0, the two GroupNorms) are staged in LDS once.  Vector-memory instructions
+// per wave and tile: 8 (the U / V rows, which land directly in the second GEMM's accumulators) + the output rows.
+//
+// seg = 0: m[p] = m_p for every pair (what lgcn_att_pairs writes).
+// seg = 16: pairs are sorted by target; within every 16-aligned group of pair rows the rows of one target are summed
+//   in pair order and the sum is written at the row of the piece's FIRST pair; the other rows are not written.
+//   The tail then adds, per target with pairs [a, b), the rows {a} U {16 j : a < 16 j < b} (relation mode
+//   LGCN_REL_RANGE16 of lgcn_agg_mlp): 12 x fewer rows through HBM and through the tail's CUs for A2A at S2.
+template <int F>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(F == 0 ? 2 : 4)))
+void k_att_pairs_ws(const PairParams p, const int seg) {
+    constexpr int RB = 4, ROWS = 64, NP = Fmt<F>::NP;
+    using TL = Tile<RB, F>;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[TL::ABUF_BYTES + TL::T_BYTES];
+    __shared__ __attribute__((aligned(16))) float s_par[7 * kC];      // wd0 [128][2] | bd0 | gd | btd | gc | btc
+    __shared__ int s_hi[ROWS], s_wi[ROWS];
+    uint16_t *A = reinterpret_cast<uint16_t *>(smem);
+    float *T = reinterpret_cast<float *>(smem + TL::ABUF_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t P = *p.n_pairs;
+    if (P < 0 || P > p.cap) P = p.cap;
+    const int64_t n_tiles = (P + ROWS - 1) / ROWS;
+    if ((int64_t)blockIdx.x >= n_tiles) return;
+
+    // this wave's slices of the two weights: [plane][K-step], channels 16 wave .. + 15
+    uint4 w1[NP][4], w2[NP][4];
+    {
+        const uint4 *B1 = reinterpret_cast<const uint4 *>(p.wpd2), *B2 = reinterpret_cast<const uint4 *>(p.wpc0e);
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int o = ((((pl * 4 + (wave >> 1)) * 4 + ks) * 2 + (wave & 1)) << 6) + lane;
+                w1[pl][ks] = B1[o];
+                w2[pl][ks] = B2[o];
+            }
+    }
+    if (tid < 2 * kC) s_par[tid] = p.wd0[tid];
+    else if (tid < 3 * kC) s_par[tid] = p.bd0[tid - 2 * kC];
+    else if (tid < 4 * kC) s_par[tid] = p.gd[tid - 3 * kC];
+    if (tid < kC) {
+        s_par[4 * kC + tid] = p.btd[tid];
+        s_par[5 * kC + tid] = p.gc[tid];
+        s_par[6 * kC + tid] = p.btc[tid];
+    }
+    const float *l_wd0 = s_par, *l_bd0 = s_par + 2 * kC, *l_gd = s_par + 3 * kC, *l_btd = s_par + 4 * kC;
+    const float *l_gc = s_par + 5 * kC, *l_btc = s_par + 6 * kC;
+
+    const int row = tid >> 3;
+    const uint16_t *arow = A + (lane & 15) * kLDB + 8 * (lane >> 4);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[RB];
+    // acc[rb] += W-slice^T x A^T (swapped operands: a lane ends up with 4 consecutive channels of row lane & 15)
+    auto gemm = [&](const uint4 (&w)[NP][4]) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int r2 = 0; r2 < RB; r2 += 2) {      // two sub-blocks' fragments at a time (register budget)
+                uint4 a[NP][2];
+#pragma unroll
+                for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        a[pl][j] = *reinterpret_cast<const uint4 *>(arow + pl * TL::PLANE + (r2 + j) * 16 * kLDB + 32 * ks);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    f32x4 c = acc[r2 + j];
+#pragma unroll
+                    for (int q = 0; q < Fmt<F>::NPROD; ++q)      // smallest terms first
+                        c = Fmt<F>::mfma(w[Fmt<F>::PB[q]][ks], a[Fmt<F>::PA[q]][j], c);
+                    acc[r2 + j] = c;
+                }
+            }
+        }
+    };
+    auto acc_to_tile = [&]() {
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+            *reinterpret_cast<f32x4 *>(T + (16 * rb + (lane & 15)) * kLDA + 16 * wave + 4 * (lane >> 4)) = acc[rb];
+    };
+
+    // pair indices and centre offsets of the first tile; later tiles: requested one tile ahead
+    int64_t tile = blockIdx.x;
+    int hi_c = -1, wi_c = 0;
+    float dx = 0.f, dy = 0.f;
+    auto fetch_idx = [&](int64_t tl, int &h, int &w) {
+        const int64_t pr = tl * ROWS + row;
+        const bool live = tl < n_tiles && pr < P;
+        h = live ? p.hi[pr] : -1;
+        w = live ? p.wi[pr] : 0;
+    };
+    auto fetch_d = [&](int h, int w, float &x, float &y) {
+        x = y = 0.f;
+        if (h >= 0) {
+            const float2 a = reinterpret_cast<const float2 *>(p.agt_ctrs)[h];
+            const float2 c = reinterpret_cast<const float2 *>(p.ctx_ctrs)[w];
+            x = a.x - c.x; y = a.y - c.y;
+        }
+    };
+    fetch_idx(tile, hi_c, wi_c);
+    fetch_d(hi_c, wi_c, dx, dy);
+    __syncthreads();          // s_par
+
+    for (; tile < n_tiles; tile += gridDim.x) {
+        const int64_t pr0 = tile * ROWS;
+        // the opaque zero keeps the row phases' per-thread addressing (the same for every tile) out of the loop
+        // pre-header: hoisted, those values would live in registers / scratch for the whole kernel (128-VGPR budget)
+        int opq = 0;
+        asm volatile("" : "+v"(opq));
+        const int tidv = tid + opq, rowv = tidv >> 3, lanev = tidv & 63;
+        // ---- e0 = ReLU(W_d0 d + b_d0) -> A planes; the tile's pair indices -> LDS; next tile's indices requested
+        lin2_relu_split<F>(A, TL::PLANE, rowv, tidv, dx, dy, l_wd0, l_bd0);
+        if ((tidv & 7) == 0) { s_hi[rowv] = hi_c; s_wi[rowv] = wi_c; }
+        int hi_n, wi_n;
+        fetch_idx(tile + gridDim.x, hi_n, wi_n);
+        __syncthreads();
+        // ---- e1 = A x W_d2
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) acc[rb] = zero4;
+        gemm(w1);
+        acc_to_tile();
+        // U[hi] + V[wi] of this lane's rows / channels: the second GEMM's accumulators start from them
+        // (registers: the U rows travel under the row phase, the V rows are requested behind it)
+        const int64_t co = 16 * wave + 4 * (lanev >> 4);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const int h = s_hi[16 * rb + (lanev & 15)];
+            acc[rb] = *reinterpret_cast<const f32x4 *>(p.U + (int64_t)(h < 0 ? 0 : h) * kC + co);
+        }
+        __syncthreads();      // T complete; every wave is done reading A
+        // ---- e = ReLU(GN_d(e1)) -> A planes
+        {
+            RowVals r = row_load(T, tidv);
+            row_gn(r, tidv, l_gd, l_btd, p.eps);
+            row_relu(r);
+            row_split_store<F>(A, TL::PLANE, rowv, tidv, r);
+        }
+        fetch_d(hi_n, wi_n, dx, dy);          // next tile's centres (its indices have landed by now)
+        {
+            f32x4 v[RB];
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const int r = 16 * rb + (lanev & 15);
+                const int w = s_hi[r] < 0 ? 0 : s_wi[r];
+                v[rb] = *reinterpret_cast<const f32x4 *>(p.V + (int64_t)w * kC + co);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = acc[rb] + v[rb];
+        }
+        // ---- t = U + V + A x W_c0e
+        gemm(w2);
+        acc_to_tile();
+        __syncthreads();
+        // ---- m_p = ReLU(GN_c(t))
+        {
+            RowVals r = row_load(T, tidv);
+            row_gn(r, tidv, l_gc, l_btc, p.eps);
+            row_relu(r);
+            const int64_t pr = pr0 + rowv;
+            if (seg == 0) {
+                if (pr < P) row_store_global(p.m + pr * kC, tidv, r);
+            } else {
+                row_store_lds(T, tidv, r);     // the thread's own 16 floats: no other thread touches them
+            }
+        }
+        if (seg != 0) {
+            __syncthreads();
+            // one thread per (channel, 16-row group): the rows of a target are summed in pair order
+            const int c = tidv & (kC - 1), g0 = (tidv >> 7) * 16;
+            int cur = s_hi[g0], first = g0;
+            float sum = 0.f;
+            if (cur >= 0) {
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const int t = s_hi[g0 + i];
+                    if (t != cur) {
+                        p.m[(pr0 + first) * kC + c] = sum;
+                        if (t < 0) { cur = -1; break; }
+                        cur = t; first = g0 + i; sum = 0.f;
+                    }
+                    sum += T[(g0 + i) * kLDA + c];
+                }
+                if (cur >= 0) p.m[(pr0 + first) * kC + c] = sum;
+            }
+        }
+        hi_c = hi_n; wi_c = wi_n;
+        __syncthreads();      // the next tile rewrites A, T and the index words
+    }
+}
+
 }  // namespace lgcn
 
 using namespace lgcn;
@@ -212,6 +411,35 @@ extern "C" int lgcn_att_fused(const lgcn_att_fused_t *ph, void *stream) {
         case LGCN_MMA_BF16X3: hipLaunchKernelGGL((k_att_fused<0>), dim3(grid), dim3(256), 0, st, p); break;
         case LGCN_MMA_F16X2: hipLaunchKernelGGL((k_att_fused<1>), dim3(grid), dim3(256), 0, st, p); break;
         default: hipLaunchKernelGGL((k_att_fused<2>), dim3(grid), dim3(256), 0, st, p); break;
+    }
+    return launch_status();
+}
+
+extern "C" int lgcn_att_pairs_ws(const float *agt_ctrs, const float *ctx_ctrs, const int32_t *hi, const int32_t *wi,
+                                 const int32_t *n_pairs, int64_t cap, const float *wd0, const float *bd0,
+                                 const float *wpd2, const float *gd, const float *btd, const float *wpc0e,
+                                 const float *U, const float *V, const float *gc, const float *btc, float eps, int mma,
+                                 int seg, float *m, void *stream) {
+    if (mma != LGCN_MMA_BF16X3 && mma != LGCN_MMA_F16X2 && mma != LGCN_MMA_BF16) return LGCN_ESHAPE;
+    if (cap < 0 || (seg != 0 && seg != 16)) return LGCN_EINVAL;
+    if (cap == 0) return LGCN_OK;
+    if (cap > 0x7ffffff0) return LGCN_ESHAPE;
+    const void *ptrs[] = {agt_ctrs, ctx_ctrs, hi, wi, n_pairs, wd0, bd0, wpd2, gd, btd, wpc0e, U, V, gc, btc, m};
+    for (const void *q : ptrs) LGCN_CHECK_PTR(q);
+    const void *al[] = {wd0, bd0, wpd2, gd, btd, wpc0e, U, V, gc, btc, m};
+    for (const void *q : al) LGCN_CHECK_ALIGN16(q);
+    PairParams p{agt_ctrs, ctx_ctrs, hi, wi, n_pairs, cap, wd0, bd0, wpd2, gd, btd, wpc0e, U, V, gc, btc, eps, m};
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const int64_t tiles = (cap + 63) / 64;
+    const int64_t slots = (int64_t)cus * (mma == LGCN_MMA_BF16X3 ? 1 : 2);
+    const unsigned grid = (unsigned)(tiles < slots ? tiles : slots);
+    hipStream_t st = (hipStream_t)stream;
+    switch (mma) {
+        case LGCN_MMA_BF16X3: hipLaunchKernelGGL((k_att_pairs_ws<0>), dim3(grid), dim3(512), 0, st, p, seg); break;
+        case LGCN_MMA_F16X2: hipLaunchKernelGGL((k_att_pairs_ws<1>), dim3(grid), dim3(512), 0, st, p, seg); break;
+        default: hipLaunchKernelGGL((k_att_pairs_ws<2>), dim3(grid), dim3(512), 0, st, p, seg); break;
     }
     return launch_status();
 }

@@ -212,9 +212,9 @@ __device__ __forceinline__ void pairs_rows_body(const float2 *agt, const int32_t
                                                 int32_t *rowcnt, const int32_t *rowptr,
                                                 const int32_t *hi_base, const int32_t *wi_base,
                                                 int32_t *hi, int32_t *wi, int64_t cap, int legacy,
-                                                int32_t *rowptr_q) {
+                                                int32_t *rowptr_q, int row_block) {
     const int lane = threadIdx.x & 63;
-    const int g = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int g = row_block * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_agt) return;
     const int sc = find_scene(agt_off, n_scenes, g);
     const int c0 = ctx_off[sc], c1 = ctx_off[sc + 1];
@@ -275,7 +275,7 @@ template <int PASS>
 __global__ __launch_bounds__(256) void k_pairs_rows(const PairsJobs jobs) {
     const PairsJob &j = jobs.j[blockIdx.y];
     pairs_rows_body<PASS>(j.agt, j.agt_off, j.ctx, j.ctx_off, j.n_scenes, j.n_agt, j.th, j.rp(), j.rp(), j.hi_base(),
-                          j.wi_base(), j.hi, j.wi, j.cap, j.legacy, j.rowptr_q);
+                          j.wi_base(), j.hi, j.wi, j.cap, j.legacy, j.rowptr_q, (int)blockIdx.x);
 }
 
 // Single block: exclusive scan of the row counts in place (rp[0..T), rp[T] = P; each thread owns a contiguous
@@ -333,6 +333,127 @@ __global__ __launch_bounds__(1024) void k_pairs_scan_bases(const PairsJobs jobs)
     pairs_scan_bases_body(j.rp(), j.n_agt, j.agt_off, j.ctx_off, j.n_scenes, j.legacy, j.cap, j.hi_base(), j.wi_base(),
                           j.n_pairs);
     if (j.n_agt == 0 && threadIdx.x == 0) j.rowptr_q[0] = 0;     // no rows: the fill pass never runs for this job
+}
+
+// ------------------------------------------------- fused index pipeline -----
+// lgcn_index_build: graph_gather + CSR plan + up to four pair searches in THREE launches (count | scan | fill)
+// instead of twelve.  At S2 every one of those launches is a few microseconds of work behind a launch boundary
+// of the same size; what the twelve cost is their number.
+//   * graph_gather is folded into the edge pass: an edge thread turns its two local indices into global ones
+//     (binary search of the segment table) and keeps them as an int32 pair for the fill pass.
+//   * the per-key counter is a 64-bit word with three 21-bit fields: [0,21) edges counted (pass 1), [21,42) slots
+//     handed out, [42,63) slots written (pass 3).  The thread that completes a key's last slot sorts the key's
+//     entries (ascending source, as k_csr_sort_rows) and writes the word back to ZERO: the counters must be zero
+//     on entry and are zero again when the launch has finished -- no zeroing launch, no separate cursor, no sort
+//     launch.
+//   * the scan of the 145 k keys is one launch of independent 4096-key tiles: tile b first sums the counters in
+//     front of it (they are L2-resident), then scans its own.
+//   * the pair searches' count / scan / fill bodies ride in the same launches as extra workgroups.
+constexpr int kIdxBits = 21;
+constexpr unsigned long long kIdxMask = (1ull << kIdxBits) - 1ull;
+constexpr int kIdxScanTile = 4096;      // 1024 threads x 4 keys
+
+struct IndexParams {
+    const int64_t *idx_local, *seg_off, *seg_base;
+    int n_seg, n_rel;
+    int64_t u_off[LGCN_MAX_REL], v_off[LGCN_MAX_REL];
+    int64_t start[LGCN_MAX_REL + 1];          // prefix of the relations' edge counts
+    int64_t n_nodes, n_keys1;                 // keys + 1
+    unsigned long long *cnt;                  // [n_keys1], zero on entry and on completion
+    int32_t *uv;                              // [2 * total] global (u, v) of every edge; u = -1: dropped
+    int32_t *rowptr, *col;
+    int edge_blocks, scan_blocks, n_jobs;
+    int job_blocks[5];                        // prefix of the pair jobs' row-block counts
+    PairsJobs jobs;
+};
+
+__device__ __forceinline__ int64_t to_global(const IndexParams &p, int64_t i) {
+    int lo = 0, hi = p.n_seg;                 // last segment with seg_off[s] <= i (as k_graph_gather)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (p.seg_off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return p.idx_local[i] + p.seg_base[lo];
+}
+
+template <int PASS>     // 0: count, 1: fill
+__global__ __launch_bounds__(256) void k_index_edges(const IndexParams p) {
+    const int bid = blockIdx.x;
+    if (bid >= p.edge_blocks) {               // pair-search workgroups
+        const int b = bid - p.edge_blocks;
+        int jn = 0;
+        while (jn + 1 < p.n_jobs && b >= p.job_blocks[jn + 1]) ++jn;
+        const PairsJob &j = p.jobs.j[jn];
+        pairs_rows_body<PASS>(j.agt, j.agt_off, j.ctx, j.ctx_off, j.n_scenes, j.n_agt, j.th, j.rp(), j.rp(), j.hi_base(),
+                              j.wi_base(), j.hi, j.wi, j.cap, j.legacy, j.rowptr_q, b - p.job_blocks[jn]);
+        return;
+    }
+    const int64_t total = p.start[p.n_rel];
+    for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < total; e += (int64_t)p.edge_blocks * blockDim.x) {
+        int r = 0;
+        while (r + 1 < p.n_rel && e >= p.start[r + 1]) ++r;
+        if (PASS == 0) {
+            const int64_t le = e - p.start[r];
+            const int64_t u = to_global(p, p.u_off[r] + le), v = to_global(p, p.v_off[r] + le);
+            const bool ok = u >= 0 && u < p.n_nodes && v >= 0 && v < p.n_nodes;     // never index out of bounds
+            p.uv[2 * e] = ok ? (int32_t)u : -1;
+            p.uv[2 * e + 1] = (int32_t)v;
+            if (ok) atomicAdd(&p.cnt[csr_key(u, r, p.n_rel)], 1ull);
+        } else {
+            const int u = p.uv[2 * e], v = p.uv[2 * e + 1];
+            if (u < 0) continue;
+            const int64_t k = csr_key(u, r, p.n_rel);
+            const int base = p.rowptr[k];
+            const unsigned long long a = atomicAdd(&p.cnt[k], 1ull << kIdxBits);
+            p.col[base + (int)((a >> kIdxBits) & kIdxMask)] = v;
+            __threadfence();                  // the slot is visible before it is counted as written
+            const unsigned long long d = atomicAdd(&p.cnt[k], 1ull << (2 * kIdxBits));
+            const int n = (int)(d & kIdxMask);
+            if ((int)((d >> (2 * kIdxBits)) & kIdxMask) + 1 == n) {     // last slot of the key: canonical order, reset
+                __threadfence();
+                volatile int32_t *c = p.col + base;
+                for (int i = 1; i < n; ++i) {
+                    const int x = c[i];
+                    int q = i - 1;
+                    while (q >= 0 && c[q] > x) { c[q + 1] = c[q]; --q; }
+                    c[q + 1] = x;
+                }
+                p.cnt[k] = 0ull;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_index_scan(const IndexParams p) {
+    __shared__ int lds[1024 / 64 + 1];
+    const int bid = blockIdx.x;
+    if (bid >= p.scan_blocks) {               // one workgroup per pair search: row scan + per-scene bases
+        const PairsJob &j = p.jobs.j[bid - p.scan_blocks];
+        pairs_scan_bases_body(j.rp(), j.n_agt, j.agt_off, j.ctx_off, j.n_scenes, j.legacy, j.cap, j.hi_base(), j.wi_base(),
+                              j.n_pairs);
+        if (j.n_agt == 0 && threadIdx.x == 0) j.rowptr_q[0] = 0;
+        return;
+    }
+    // counters in front of this tile
+    const int64_t t0 = (int64_t)bid * kIdxScanTile;
+    int part = 0;
+    for (int64_t i = threadIdx.x; i < t0; i += 1024) part += (int)(p.cnt[i] & kIdxMask);
+    int before;
+    block_exclusive_scan<1024>(part, &before, lds);
+    const int64_t b = t0 + 4 * (int64_t)threadIdx.x;
+    int v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        v[k] = b + k < p.n_keys1 ? (int)(p.cnt[b + k] & kIdxMask) : 0;
+        sum += v[k];
+    }
+    int tile_total;
+    int off = block_exclusive_scan<1024>(sum, &tile_total, lds) + before;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (b + k < p.n_keys1) p.rowptr[b + k] = off;
+        off += v[k];
+    }
 }
 
 // rowptr and cursor of the CSR plan zeroed in one launch (two memset nodes cost a launch boundary each)
@@ -488,6 +609,70 @@ int lgcn_pairs_build(const float *agt_ctrs, const int32_t *agt_off, const float 
     q.n_scenes = n_scenes; q.legacy_offsets = legacy_offsets; q.n_agt = n_agt; q.n_ctx = n_ctx;
     q.dist_th = dist_th; q.pad_ = 0; q.hi = hi; q.wi = wi; q.cap = cap; q.n_pairs = n_pairs; q.rowptr = rowptr; q.ws = ws;
     return lgcn_pairs_build_multi(&q, 1, stream);
+}
+
+int64_t lgcn_index_uv_elems(int64_t n_edges) { return n_edges < 0 ? (int64_t)LGCN_EINVAL : 2 * n_edges; }
+
+int lgcn_index_build(const lgcn_index_t *ph, void *stream) {
+    LGCN_CHECK_PTR(ph);
+    const lgcn_index_t &q = *ph;
+    if (q.n_rel < 1 || q.n_rel > LGCN_MAX_REL || q.n_nodes < 0 || q.n_seg < 1 || q.n_jobs < 0 || q.n_jobs > 4 || q.n_elem < 0)
+        return LGCN_EINVAL;
+    LGCN_CHECK_PTR(q.rowptr); LGCN_CHECK_PTR(q.cnt);
+    if (((uintptr_t)q.cnt & 7u) != 0) return LGCN_EALIGN;
+    if (q.n_jobs > 0) LGCN_CHECK_PTR(q.jobs);
+    IndexParams p;
+    p.idx_local = q.idx_local; p.seg_off = q.seg_off; p.seg_base = q.seg_base; p.n_seg = q.n_seg; p.n_rel = q.n_rel;
+    p.start[0] = 0;
+    for (int r = 0; r < q.n_rel; ++r) {
+        if (q.n_edges[r] < 0 || q.u_off[r] < 0 || q.v_off[r] < 0 || q.u_off[r] + q.n_edges[r] > q.n_elem ||
+            q.v_off[r] + q.n_edges[r] > q.n_elem)
+            return LGCN_EINVAL;
+        p.u_off[r] = q.u_off[r]; p.v_off[r] = q.v_off[r];
+        p.start[r + 1] = p.start[r] + q.n_edges[r];
+    }
+    for (int r = q.n_rel; r < LGCN_MAX_REL; ++r) { p.u_off[r] = p.v_off[r] = 0; p.start[r + 1] = p.start[q.n_rel]; }
+    const int64_t total = p.start[q.n_rel];
+    // a key's three counter fields hold 21 bits each: no key can exceed the total edge count
+    if (total > (int64_t)kIdxMask || q.n_nodes > 0x7fffffff) return LGCN_ESHAPE;
+    const int64_t nk1 = lgcn_csr_rowptr_elems(q.n_nodes, q.n_rel);
+    if (nk1 > (int64_t)1 << 22) return LGCN_ESHAPE;      // the one-launch scan re-reads the counters in front of a tile
+    if (total > 0) {
+        LGCN_CHECK_PTR(q.idx_local); LGCN_CHECK_PTR(q.seg_off); LGCN_CHECK_PTR(q.seg_base);
+        LGCN_CHECK_PTR(q.col); LGCN_CHECK_PTR(q.uv);
+    }
+    p.n_nodes = q.n_nodes; p.n_keys1 = nk1;
+    p.cnt = reinterpret_cast<unsigned long long *>(q.cnt); p.uv = q.uv; p.rowptr = q.rowptr; p.col = q.col;
+    p.n_jobs = q.n_jobs;
+    p.job_blocks[0] = 0;
+    for (int k = 0; k < 4; ++k) {
+        if (k < q.n_jobs) {
+            const lgcn_pairs_job_t &jq = q.jobs[k];
+            const int rc = pairs_job_check(jq);
+            if (rc != LGCN_OK) return rc;
+            PairsJob &d = p.jobs.j[k];
+            d.agt = (const float2 *)jq.agt_ctrs; d.agt_off = jq.agt_off;
+            d.ctx = (const float2 *)jq.ctx_ctrs; d.ctx_off = jq.ctx_off;
+            d.n_scenes = jq.n_scenes; d.n_agt = (int)jq.n_agt; d.legacy = jq.legacy_offsets; d.th = jq.dist_th;
+            d.hi = jq.hi; d.wi = jq.wi; d.cap = jq.cap; d.n_pairs = jq.n_pairs; d.rowptr_q = jq.rowptr; d.ws = jq.ws;
+            p.job_blocks[k + 1] = p.job_blocks[k] + (int)((jq.n_agt + 3) / 4);
+        } else {
+            if (k > 0) p.jobs.j[k] = p.jobs.j[0];
+            p.job_blocks[k + 1] = p.job_blocks[k];
+        }
+    }
+    if (q.n_jobs == 0) {
+        PairsJob z{};
+        for (int k = 0; k < 4; ++k) p.jobs.j[k] = z;
+    }
+    p.edge_blocks = total > 0 ? (int)grid_for(total, 256, 1024) : 0;
+    p.scan_blocks = (int)((nk1 + kIdxScanTile - 1) / kIdxScanTile);
+    hipStream_t st = (hipStream_t)stream;
+    const unsigned g13 = (unsigned)(p.edge_blocks + p.job_blocks[4]);
+    if (g13 > 0) hipLaunchKernelGGL((k_index_edges<0>), dim3(g13), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(k_index_scan, dim3((unsigned)(p.scan_blocks + q.n_jobs)), dim3(1024), 0, st, p);
+    if (g13 > 0) hipLaunchKernelGGL((k_index_edges<1>), dim3(g13), dim3(256), 0, st, p);
+    return launch_status();
 }
 
 int lgcn_widen_i32(const int32_t *in, const int32_t *n_dev, int64_t cap, int64_t *out, void *stream) {

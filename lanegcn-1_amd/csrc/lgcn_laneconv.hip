@@ -94,8 +94,9 @@ __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
     const int64_t n = (int64_t)b * p.M + tid;
     const bool row_ok = tid < p.M && n < p.n_nodes;
 
+    const int nt = blockDim.x;          // 64, 128 or 256 threads: the smallest multiple of a wave that covers M rows
     auto clear = [&]() {
-        for (int i = tid; i < kLcHash; i += 256) { hkey[i] = -1; hrow[i] = 0x7fffffff; hval[i] = -1; }
+        for (int i = tid; i < kLcHash; i += nt) { hkey[i] = -1; hrow[i] = 0x7fffffff; hval[i] = -1; }
     };
     auto finalize = [&](int u0, int n_live, int n_src, int span) {     // caller: all threads, followed by a barrier
         if (tid < 4) {
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
         }
     };
 
+    if (tid < 4) { s_w[tid] = 0; s_cnt[tid] = 0; }      // waves the launch does not have contribute nothing
     if (tid < u_end - u_begin) {     // headers of non-start units: no item
         int32_t *h = hdr + ((int64_t)b * kLcUnits + u_begin + tid) * kLcHdr;
 #pragma unroll
@@ -327,10 +329,11 @@ void k_lc_tile(const LcTileParams p) {
     // from the argument segment -- an s_load plus an lgkmcnt(0) wait, which also drains the LDS reads in flight)
     const float *wreg[kLcUnits];
 #pragma unroll
-    for (int u = 0; u < kLcUnits; ++u) {
-        wreg[u] = p.wp[u];
-        asm volatile("" : "+s"(wreg[u]));
-    }
+    for (int u = 0; u < kLcUnits; ++u) wreg[u] = p.wp[u];
+    static_assert(kLcUnits == 15, "the pin below lists 15 pointers");
+    asm volatile("" : "+s"(wreg[0]), "+s"(wreg[1]), "+s"(wreg[2]), "+s"(wreg[3]), "+s"(wreg[4]), "+s"(wreg[5]), "+s"(wreg[6]),
+                 "+s"(wreg[7]), "+s"(wreg[8]), "+s"(wreg[9]), "+s"(wreg[10]), "+s"(wreg[11]), "+s"(wreg[12]), "+s"(wreg[13]),
+                 "+s"(wreg[14]));      // one statement: the argument loads are issued together, one wait
     for (int u0 = p.gstart[g]; u0 < uend;) {
         const int64_t item = (int64_t)b * kLcUnits + u0;
         const int4 h = *reinterpret_cast<const int4 *>(hdr + item * kLcHdr);
@@ -793,7 +796,9 @@ int lgcn_lc_plan_build(const int32_t *rowptr, const int32_t *col, int64_t n_node
     for (int g = n_groups + 1; g < kLcUnits + 2; ++g) p.gstart[g] = gstart_host[n_groups];
     p.plan = plan;
     const int64_t n_blocks = (n_nodes + rows_per_block - 1) / rows_per_block;
-    hipLaunchKernelGGL(k_lc_plan, dim3((unsigned)(n_blocks * n_groups)), dim3(256), 0, (hipStream_t)stream, p);
+    // one thread per row of the block: short row blocks run as one or two waves (their barriers cost next to nothing)
+    const unsigned nt = rows_per_block <= 64 ? 64u : rows_per_block <= 128 ? 128u : 256u;
+    hipLaunchKernelGGL(k_lc_plan, dim3((unsigned)(n_blocks * n_groups)), dim3(nt), 0, (hipStream_t)stream, p);
     return launch_status();
 }
 
@@ -832,7 +837,9 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
     t.exp = 0;
 #ifdef LGCN_STAMPS
     t.stamps = g_lc_stamps;
-    { const char *e = getenv("LGCN_EXP_LC"); t.exp = e ? atoi(e) : 0; }
+#endif
+#ifdef LGCN_TUNING
+    { const char *e = getenv("LGCN_EXP_LC"); t.exp = e ? atoi(e) : 0; }      // diagnostic build: work-skipping knobs
 #endif
     LcCombParams c{q.part, q.n_rows, M, q.n_groups, q.x, q.wp2, q.gn1_g, q.gn1_b, q.gn2_g, q.gn2_b, q.eps, q.out};
     const unsigned grid1 = (unsigned)(n_blocks * q.n_groups);

@@ -528,6 +528,9 @@ static int validate_agg(const lgcn_agg_mlp_t &p, bool *need_col_out) {
                 if (p.rel[r].ridx < 0 || p.rel[r].ridx >= p.n_rel_csr) return LGCN_EINVAL;
                 need_rowptr = need_col = true; break;
             case LGCN_REL_RANGE: need_rowptr = true; break;
+            case LGCN_REL_RANGE16:          // split-precision kernels only
+                if (p.mma == LGCN_MMA_F32) return LGCN_ESHAPE;
+                need_rowptr = true; break;
             default: return LGCN_EINVAL;
         }
     }
@@ -535,7 +538,7 @@ static int validate_agg(const lgcn_agg_mlp_t &p, bool *need_col_out) {
     if (need_col) LGCN_CHECK_PTR(p.col);
     if (need_col) {   // one rowptr per launch: a CSR plan and a RANGE prefix cannot be mixed
         for (int r = 0; r < p.n_rel; ++r)
-            if (p.rel[r].mode == LGCN_REL_RANGE) return LGCN_EINVAL;
+            if (p.rel[r].mode == LGCN_REL_RANGE || p.rel[r].mode == LGCN_REL_RANGE16) return LGCN_EINVAL;
     }
     if (p.flags & LGCN_F_GN1) { LGCN_CHECK_PTR(p.gn1_g); LGCN_CHECK_PTR(p.gn1_b); LGCN_CHECK_ALIGN16(p.gn1_g); LGCN_CHECK_ALIGN16(p.gn1_b); }
     if (p.flags & LGCN_F_GEMM2) { LGCN_CHECK_PTR(p.wp2); LGCN_CHECK_ALIGN16(p.wp2); }

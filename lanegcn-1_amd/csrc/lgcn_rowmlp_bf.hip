@@ -128,7 +128,7 @@ __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const l
             b[it] = rp[o] + adj;
             e[it] = rp[o + 1] + adj;
         }
-    } else if (mode == LGCN_REL_RANGE) {
+    } else if (mode == LGCN_REL_RANGE || mode == LGCN_REL_RANGE16) {
 #pragma unroll
         for (int it = 0; it < IT; ++it) { b[it] = ix.rng[it * 8 + hw]; e[it] = ix.rng[it * 8 + hw + 1]; }
     } else {
@@ -148,7 +148,15 @@ __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const l
     auto row_of = [&](int j) -> unsigned { return mode != LGCN_REL_CSR ? (unsigned)j : (unsigned)(LDSCOL ? ix.col[j] : p.col[j]); };
     auto load = [&](unsigned r) -> f32x4 { return src[((uint64_t)r << 5) + l]; };
     // edges j .. e-1 of one row added to acc in index order, four loads in flight
+    // RANGE16: the rows of a segment [b, e) that hold data are b and the multiples of 16 inside (b, e)
+    // (lgcn_att_pairs_ws, seg = 16: per-target sums of 16-aligned pieces, written at each piece's first row)
+    constexpr bool STEP16 = MODE == LGCN_REL_RANGE16;
+    auto nxt = [&](int j) -> int { return STEP16 ? ((j >> 4) + 1) << 4 : j + 1; };
     auto tail = [&](f32x4 acc, int j, int end) -> f32x4 {
+        if (STEP16) {
+            for (; j < end; j += 16) acc = acc + load((unsigned)j);
+            return acc;
+        }
         if (MODE == LGCN_REL_RANGE && RB == 1) {    // Att segment sums (tens of rows per target): eight in flight where registers allow
             for (; j + 7 < end; j += 8) {
                 f32x4 y[8];
@@ -169,7 +177,7 @@ __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const l
     XRows<F, Ring, IT> x(ring);
     bool more = false;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) more = more | (b[it] + 1 < e[it]);
+    for (int it = 0; it < IT; ++it) more = more | (nxt(b[it]) < e[it]);
     const bool any2 = MODE != LGCN_REL_IDENT && __any(more);   // some row of this wave has a second edge
     unsigned r0[IT];
 #pragma unroll
@@ -183,7 +191,7 @@ __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const l
 #pragma unroll
         for (int it = 0; it < IT; ++it) {
             f32x4 v = zero;
-            if (b[it] + 1 < e[it]) v = load(row_of(b[it] + 1));
+            if (nxt(b[it]) < e[it]) v = load(row_of(nxt(b[it])));
             x.set(it, v);
         }
     }
@@ -194,10 +202,10 @@ __device__ __forceinline__ void gather_mode(uint16_t *__restrict__ Abuf, const l
         for (int it = 0; it < IT; ++it) s[it >> 1][it & 1] = s[it >> 1][it & 1] + x.get(it);
         more = false;
 #pragma unroll
-        for (int it = 0; it < IT; ++it) more = more | (b[it] + 2 < e[it]);
+        for (int it = 0; it < IT; ++it) more = more | (nxt(nxt(b[it])) < e[it]);
         if (__any(more)) {   // in-degree > 2 (rare in lane graphs, the rule for Att's RANGE sums)
 #pragma unroll
-            for (int it = 0; it < IT; ++it) s[it >> 1][it & 1] = tail(s[it >> 1][it & 1], b[it] + 2, e[it]);
+            for (int it = 0; it < IT; ++it) s[it >> 1][it & 1] = tail(s[it >> 1][it & 1], nxt(nxt(b[it])), e[it]);
         }
     }
 #pragma unroll
@@ -214,6 +222,7 @@ __device__ __forceinline__ void gather_rel(uint16_t *__restrict__ Abuf, const lg
     const int mode = p.rel[ri].mode;     // wave-uniform
     if (mode == LGCN_REL_IDENT) gather_mode<RB, F, LGCN_REL_IDENT, false>(Abuf, p, ri, tile, gt, ix, cadj, s, ring);
     else if (KIND == 1) gather_mode<RB, F, LGCN_REL_CSR, LDSCOL>(Abuf, p, ri, tile, gt, ix, cadj, s, ring);
+    else if (mode == LGCN_REL_RANGE16) gather_mode<RB, F, LGCN_REL_RANGE16, false>(Abuf, p, ri, tile, gt, ix, cadj, s, ring);
     else gather_mode<RB, F, LGCN_REL_RANGE, false>(Abuf, p, ri, tile, gt, ix, cadj, s, ring);
 }
 
@@ -283,7 +292,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
             }
         }
     } else if (has_rng) {
-        if (wave == 7 && lane < p.n_rel && p.rel[lane].mode == LGCN_REL_RANGE) {
+        if (wave == 7 && lane < p.n_rel && (p.rel[lane].mode == LGCN_REL_RANGE || p.rel[lane].mode == LGCN_REL_RANGE16)) {
             a0[0] = p.rowptr[row0 < p.n_rows ? row0 : p.n_rows];
             a1[0] = p.rowptr[row0 + ROWS < p.n_rows ? row0 + ROWS : p.n_rows];
         }

@@ -10,6 +10,8 @@ a hipGraph (``capture``) and replayed with one host call.
 from dataclasses import dataclass
 from typing import Dict, List, Optional
 
+import os
+
 import numpy as np
 import torch
 
@@ -181,6 +183,8 @@ class HotPathEngine:
         # scenes/s) and a loss with four graphs in flight (61 k vs 90 k) -> off by default.
         self.branches = branches
         self._side = None
+        # the integer stage as lgcn_index_build (3 launches) instead of 12; False: the separate entry points
+        self.fused_index = os.environ.get("LGCN_INDEX", "fused") == "fused"
 
     @torch.no_grad()
     def forward(self, fb: FlatBatch, actors: torch.Tensor, stages: bool = False,
@@ -209,13 +213,17 @@ class HotPathEngine:
         bufs = [ops.pairs_alloc(s[0].shape[0], fb.n_scenes, s[5], dev) for s in searches]   # on the main stream
         if side is not None:
             side.wait_stream(main)
-        with torch.cuda.stream(side if side is not None else main):
-            pairs = ops.pairs_build_multi(searches, self.legacy_offsets, bufs=bufs)   # three sets, three launches
-        # graph_gather (lanegcn.py:171-209) + CSR plan
-        g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
-        us = [g64[a:b] for (a, b), _ in fb.rel_slices]
-        vs = [g64[a:b] for _, (a, b) in fb.rel_slices]
-        plan = ops.csr_build(us, vs, fb.n_nodes)
+        if side is None and self.fused_index and ops.index_fused_ok(fb.n_nodes, len(fb.rel_slices), sum(fb.n_edges)):
+            # graph_gather (lanegcn.py:171-209) + CSR plan + the three pair searches: three launches in all
+            plan, pairs = ops.index_build(fb.idx_local, fb.seg_off, fb.seg_base, fb.rel_slices, fb.n_nodes, searches,
+                                          self.legacy_offsets, bufs=bufs)
+        else:
+            with torch.cuda.stream(side if side is not None else main):
+                pairs = ops.pairs_build_multi(searches, self.legacy_offsets, bufs=bufs)   # three sets, three launches
+            g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
+            us = [g64[a:b] for (a, b), _ in fb.rel_slices]
+            vs = [g64[a:b] for _, (a, b) in fb.rel_slices]
+            plan = ops.csr_build(us, vs, fb.n_nodes)
         # MapNet (lanegcn.py:311-363)
         feat = self.map_net.stem(fb.node_ctrs, fb.node_feats)
         feat = M.lane_conv(self.map_net.fuse, feat, plan, fb.num_scales, impl=self.lane_impl)

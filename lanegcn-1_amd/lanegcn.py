@@ -415,12 +415,15 @@ class Att(nn.Module):
             main.wait_stream(side)
         else:
             U, V = ops.agg_mlp_pair(u_kw, v_kw)
+        # few targets with many pairs each (M2A, A2A: at least as many context rows as targets): the pair kernel
+        # sums the rows of a target inside every 16-aligned group, and the tail reads one row per piece
+        seg = 16 if ops.att_pairs_impl() == "ws" and ctx.shape[0] >= T else 0
         m = ops.att_pairs(ps, self.dist[0].weight, self.dist[0].bias, ops.packed(self.dist[2].linear.weight),
                           _gn(self.dist[2].norm), ops.packed(c0.linear.weight, 0, 128), U, V, _gn(c0.norm),
-                          eps=c0.norm.eps)
+                          eps=c0.norm.eps, seg=seg)
         # ctx.1 is linear: apply it to the per-target segment sum instead of every pair
         rels = [ops.RelSpec(agts, ops.packed(self.agt.weight)),
-                ops.RelSpec(m, ops.packed(self.ctx[1].weight), L.REL_RANGE)]
+                ops.RelSpec(m, ops.packed(self.ctx[1].weight), L.REL_RANGE16 if seg else L.REL_RANGE)]
         return ops.agg_mlp(T, rels, _FULL, rowptr=ps.rowptr, gn1=_gn(self.norm),
                            wp2=ops.packed(lin.linear.weight), gn2=_gn(lin.norm), res=agts, eps=self.norm.eps,
                            tag="att_post")
@@ -649,7 +652,7 @@ def _net_replay_or_run(self, eng, hfb, feats, rot, orig, sizes):
     is uploaded and run eagerly.  Net.graph_cache = False disables it."""
     m = hfb.meta
     sig = (m["n_nodes"], m["n_actors"], tuple(m["n_edges"]), tuple(sizes), m["cap_a2m"], m["cap_a2a"], ops.get_mma(),
-           ops.att_impl(), ops.laneconv_impl(), Att.strict, sum(p._version for p in ops.module_params(self)))
+           ops.att_impl(), ops.att_pairs_impl(), ops.laneconv_impl(), Att.strict, sum(p._version for p in ops.module_params(self)))
     st = self.__dict__.setdefault("_graph_state", {"last": None, "sig": None, "graph": None})
     if Net.graph_cache and st["graph"] is not None and st["sig"] == sig:
         g, gfb, gin, gout = st["graph"]

@@ -276,7 +276,15 @@ def pairs_build_multi(searches, legacy_offsets: bool = True, bufs=None) -> List[
     n = len(searches)
     if n < 1 or n > 4:
         raise L.LgcnError("pairs_build_multi: 1..4 searches")
-    jobs = (L.PairsJob * n)()
+    jobs, out, keep = _pairs_jobs(searches, legacy_offsets, bufs)
+    L.check(lib.lgcn_pairs_build_multi(jobs, n, _stream()), "lgcn_pairs_build_multi")
+    return out
+
+
+def _pairs_jobs(searches, legacy_offsets, bufs):
+    """ctypes job array + PairSets + tensors to keep alive for lgcn_pairs_build_multi / lgcn_index_build."""
+    n = len(searches)
+    jobs = (L.PairsJob * max(n, 1))()
     out, keep = [], []
     for k, (agt_ctrs, agt_off, ctx_ctrs, ctx_off, dist_th, cap) in enumerate(searches):
         agt_ctrs = _dev(agt_ctrs, torch.float32, "agt_ctrs")
@@ -285,7 +293,7 @@ def pairs_build_multi(searches, legacy_offsets: bool = True, bufs=None) -> List[
         ctx_off = _dev(ctx_off, torch.int32, "ctx_off")
         B = agt_off.numel() - 1
         if ctx_off.numel() != B + 1 or B < 1:
-            raise L.LgcnError("pairs_build_multi: offset tables must both have B+1 entries")
+            raise L.LgcnError("pair search: offset tables must both have B+1 entries")
         T, S = agt_ctrs.shape[0], ctx_ctrs.shape[0]
         hi, wi, n_pairs, rowptr, ws = bufs[k] if bufs is not None else pairs_alloc(T, B, cap, agt_ctrs.device)
         j = jobs[k]
@@ -293,10 +301,68 @@ def pairs_build_multi(searches, legacy_offsets: bool = True, bufs=None) -> List[
         j.n_scenes, j.legacy_offsets, j.n_agt, j.n_ctx, j.dist_th = B, int(bool(legacy_offsets)), T, S, float(dist_th)
         j.hi, j.wi, j.cap = hi.data_ptr(), wi.data_ptr(), cap
         j.n_pairs, j.rowptr, j.ws = n_pairs.data_ptr(), rowptr.data_ptr(), ws.data_ptr()
-        keep += [agt_ctrs, ctx_ctrs, agt_off, ctx_off, ws]    # ws must outlive the launch below (nothing else holds it)
+        keep += [agt_ctrs, ctx_ctrs, agt_off, ctx_off, ws]    # ws must outlive the launch (nothing else holds it)
         out.append(PairSet(hi, wi, n_pairs, rowptr, cap, T, agt_ctrs, ctx_ctrs))
-    L.check(lib.lgcn_pairs_build_multi(jobs, n, _stream()), "lgcn_pairs_build_multi")
-    return out
+    return jobs, out, keep
+
+
+# Counter words of lgcn_index_build: zero on entry, zero again on completion.  One buffer per (device, stream, size),
+# created zeroed on first use -- make that first use an eager call (a buffer first created under stream capture is
+# zeroed by a captured fill, i.e. on every replay: correct, but a launch the design is there to save).
+_index_cnt = {}
+
+
+def index_counters(n_words: int, device) -> torch.Tensor:
+    key = (torch.device(device), torch.cuda.current_stream().cuda_stream, n_words)
+    buf = _index_cnt.get(key)
+    if buf is None:
+        buf = torch.zeros(n_words, dtype=torch.int64, device=device)
+        _index_cnt[key] = buf
+    return buf
+
+
+def reset_index_counters():
+    """Drop the cached counter buffers (after a forward that was aborted between the count and the fill launches)."""
+    _index_cnt.clear()
+
+
+def index_fused_ok(n_nodes: int, n_rel: int, n_edges_total: int) -> bool:
+    """Whether lgcn_index_build takes this size (else: graph_gather_indices + csr_build + pairs_build_multi)."""
+    lib = L.load()
+    return n_edges_total < (1 << 21) and lib.lgcn_csr_rowptr_elems(n_nodes, n_rel) <= (1 << 22)
+
+
+def index_build(idx_local: torch.Tensor, seg_off: torch.Tensor, seg_base: torch.Tensor, rel_slices, n_nodes: int,
+                searches=(), legacy_offsets: bool = True, bufs=None):
+    """graph_gather + CSR plan + the pair searches in three launches (lgcn_index_build).  rel_slices: per relation
+    ((u_begin, u_end), (v_begin, v_end)) element ranges of idx_local.  Returns (LanePlan, [PairSet])."""
+    lib = L.load()
+    idx_local = _dev(idx_local, torch.int64, "idx_local")
+    seg_off = _dev(seg_off, torch.int64, "seg_off")
+    seg_base = _dev(seg_base, torch.int64, "seg_base")
+    n_rel = len(rel_slices)
+    if n_rel < 1 or n_rel > L.MAX_REL or len(searches) > 4:
+        raise L.LgcnError("index_build: 1..%d relations, <= 4 pair searches" % L.MAX_REL)
+    dev = idx_local.device
+    ne = [int(ub - ua) for (ua, ub), _ in rel_slices]
+    nk1 = lib.lgcn_csr_rowptr_elems(n_nodes, n_rel)
+    rowptr = torch.empty(nk1, dtype=torch.int32, device=dev)
+    col = torch.empty(max(sum(ne), 1), dtype=torch.int32, device=dev)
+    uv = torch.empty(max(2 * sum(ne), 2), dtype=torch.int32, device=dev)
+    cnt = index_counters(nk1, dev)
+    jobs, pairs, keep = _pairs_jobs(searches, legacy_offsets, bufs)
+    p = L.Index()
+    p.idx_local, p.n_elem = idx_local.data_ptr(), idx_local.numel()
+    p.seg_off, p.seg_base, p.n_seg, p.n_rel = seg_off.data_ptr(), seg_base.data_ptr(), seg_base.numel(), n_rel
+    for r, ((ua, ub), (va, vb)) in enumerate(rel_slices):
+        if vb - va != ub - ua:
+            raise L.LgcnError("index_build: u and v runs differ in length")
+        p.u_off[r], p.v_off[r], p.n_edges[r] = ua, va, ub - ua
+    p.n_nodes = n_nodes
+    p.rowptr, p.col, p.cnt, p.uv = rowptr.data_ptr(), col.data_ptr(), cnt.data_ptr(), uv.data_ptr()
+    p.jobs, p.n_jobs = C.cast(jobs, C.c_void_p).value if len(searches) else 0, len(searches)
+    L.check(lib.lgcn_index_build(C.byref(p), _stream()), "lgcn_index_build")
+    return LanePlan(rowptr, col, n_rel, n_nodes, ne), pairs
 
 
 # ------------------------------------------------------------------ weight packing
@@ -714,14 +780,38 @@ def mapnet_input(ctrs, feats, wa1, ba1, wpa2, gn_a, ws1, bs1, wps2, gn_s, eps=EP
     return out
 
 
-def att_pairs(ps: PairSet, wd0, bd0, wpd2, gn_d, wpc0e, U, V, gn_c, m=None, eps=EPS, tag="att_pairs"):
+# Per-pair MLP of Att: "ws" (default in the 16-bit-plane modes) = lgcn_att_pairs_ws, both weights in registers;
+# "stream" = lgcn_att_pairs, weight fragments streamed per 32-pair tile (the only one in f32).
+_att_pairs_impl = os.environ.get("LGCN_ATT_PAIRS", "ws")
+
+
+def set_att_pairs_impl(name: str):
+    global _att_pairs_impl
+    if name not in ("ws", "stream"):
+        raise L.LgcnError("att pairs impl must be 'ws' or 'stream'")
+    _att_pairs_impl = name
+
+
+def att_pairs_impl() -> str:
+    return "stream" if _mma == L.MMA_F32 else _att_pairs_impl
+
+
+def att_pairs(ps: PairSet, wd0, bd0, wpd2, gn_d, wpc0e, U, V, gn_c, m=None, eps=EPS, seg=0, tag="att_pairs"):
+    """m [cap,128] of lgcn_att_pairs / lgcn_att_pairs_ws.  seg = 16 (ws only): per-target sums of 16-aligned
+    pieces at each piece's first row; hand m to agg_mlp as a REL_RANGE16 relation."""
     lib = L.load()
     if m is None:
         m = torch.empty((max(ps.cap, 1), C_FEAT), dtype=torch.float32, device=U.device)
+    args = (_ptr(ps.agt_ctrs), _ptr(ps.ctx_ctrs), _ptr(ps.hi), _ptr(ps.wi), _ptr(ps.n_pairs),
+            ps.cap, _ptr(wd0), _ptr(bd0), _ptr(wpd2), _ptr(gn_d[0]), _ptr(gn_d[1]), _ptr(wpc0e),
+            _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _mma)
     with _Timed(tag):
-        rc = lib.lgcn_att_pairs(_ptr(ps.agt_ctrs), _ptr(ps.ctx_ctrs), _ptr(ps.hi), _ptr(ps.wi), _ptr(ps.n_pairs),
-                                ps.cap, _ptr(wd0), _ptr(bd0), _ptr(wpd2), _ptr(gn_d[0]), _ptr(gn_d[1]), _ptr(wpc0e),
-                                _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _mma, _ptr(m), _stream())
+        if att_pairs_impl() == "ws":
+            rc = lib.lgcn_att_pairs_ws(*args, seg, _ptr(m), _stream())
+        elif seg != 0:
+            raise L.LgcnError("att_pairs: seg needs the weight-stationary kernel (16-bit-plane modes)")
+        else:
+            rc = lib.lgcn_att_pairs(*args, _ptr(m), _stream())
     L.check(rc, "lgcn_att_pairs")
     return m
 

@@ -527,6 +527,52 @@ def test_pairs_build_multi_equals_single_searches(hip):
             assert torch.equal(pm.rowptr, ps.rowptr)
 
 
+def test_fused_index_stage_is_bit_identical(hip):
+    """lgcn_index_build (graph_gather + CSR plan + pair searches in three launches, self-cleaning counters) against the
+    separate entry points: same rowptr / col / pairs bit for bit; twice in a row (the counters must come back to
+    zero); on ragged scenes, a multigraph with duplicate edges and in-degree > 2, and a batch without any pair job."""
+    M, ops = hip
+    from lanegcn_amd import data as gen
+    from lanegcn_amd.engine import collate_flat
+    cfg = M.config
+    for seed, n_scenes in ((5, 3), (6, 7)):
+        fb = collate_flat(gen.synth_batch("S2", seed=seed, n_scenes=n_scenes))
+        g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
+        want = ops.csr_build([g64[a:b] for (a, b), _ in fb.rel_slices], [g64[a:b] for _, (a, b) in fb.rel_slices], fb.n_nodes)
+        searches = ((fb.node_ctrs, fb.node_off, fb.actor_ctrs, fb.actor_off, cfg["actor2map_dist"], fb.cap_a2m),
+                    (fb.actor_ctrs, fb.actor_off, fb.node_ctrs, fb.node_off, cfg["map2actor_dist"], fb.cap_a2m),
+                    (fb.actor_ctrs, fb.actor_off, fb.actor_ctrs, fb.actor_off, cfg["actor2actor_dist"], fb.cap_a2a))
+        want_pairs = ops.pairs_build_multi(searches, True)
+        assert ops.index_fused_ok(fb.n_nodes, len(fb.rel_slices), sum(fb.n_edges))
+        for rep in range(2):
+            plan, pairs = ops.index_build(fb.idx_local, fb.seg_off, fb.seg_base, fb.rel_slices, fb.n_nodes, searches, True)
+            assert torch.equal(plan.rowptr, want.rowptr) and torch.equal(plan.col, want.col), (seed, rep)
+            assert plan.n_edges == want.n_edges
+            for got, ref in zip(pairs, want_pairs):
+                P = ref.count()
+                assert got.count() == P
+                assert torch.equal(got.hi[:P], ref.hi[:P]) and torch.equal(got.wi[:P], ref.wi[:P])
+                assert torch.equal(got.rowptr, ref.rowptr)
+            cnt = ops.index_counters(plan.rowptr.numel(), plan.rowptr.device)
+            assert int(cnt.abs().sum()) == 0
+    # a multigraph given as ONE segment per run (local = global), no pair job
+    rng = np.random.default_rng(3)
+    n, us, vs = 16 * 9 + 3, [], []
+    for r in range(5):
+        m = 0 if r == 3 else int(rng.integers(40, 400))
+        us.append(torch.from_numpy(rng.integers(0, n, m)))
+        vs.append(torch.from_numpy(rng.integers(0, n, m)))
+    flat = torch.cat([t for pair in zip(us, vs) for t in pair]).cuda()
+    lens = [len(t) for pair in zip(us, vs) for t in pair]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    rel_slices = [((int(offs[2 * r]), int(offs[2 * r + 1])), (int(offs[2 * r + 1]), int(offs[2 * r + 2]))) for r in range(5)]
+    seg_off = torch.tensor(offs[:-1], dtype=torch.int64).cuda()
+    seg_base = torch.zeros(len(lens), dtype=torch.int64).cuda()
+    want = ops.csr_build([u.cuda() for u in us], [v.cuda() for v in vs], n)
+    plan, pairs = ops.index_build(flat, seg_off, seg_base, rel_slices, n)
+    assert pairs == [] and torch.equal(plan.rowptr, want.rowptr) and torch.equal(plan.col, want.col)
+
+
 @pytest.mark.parametrize("shape", [(1600, 32, 20), (37, 64, 10), (5, 128, 5), (130, 128, 20), (3, 7, 3)])
 def test_gn_cl_vs_torch_group_norm(hip, shape):
     """lgcn_gn_cl = GroupNorm(1 group over (C, L)) [+ res] [ReLU] in one launch vs torch's fp64 GroupNorm on the CPU."""
@@ -669,6 +715,63 @@ def test_att_fused_launch_vs_reference_captures(gcase, golden, hip, mma_mode):
     finally:
         os.environ.pop("LGCN_ATT_TT", None)
         ops.set_att_impl("split")
+
+
+def test_att_pairs_weight_stationary_and_pieces(gcase, golden, hip, mma_mode):
+    """lgcn_att_pairs_ws (weights in registers, 64-pair tiles): (1) seg = 0 writes the same pair rows as the
+    streaming kernel; (2) seg = 16 writes exactly the per-target sums of the 16-aligned pieces, at the piece's first
+    row, and touches no other row; (3) the whole hot path with either pair kernel meets the reference captures."""
+    M, ops = hip
+    if mma_mode == "f32":
+        pytest.skip("split-precision kernel")
+    scenes, _, mods = gcase
+    actors = torch.from_numpy(golden["actors_in"])
+    # (3) both implementations end to end
+    try:
+        for impl in ("stream", "ws"):
+            ops.set_att_pairs_impl(impl)
+            out, _ = run_hot_path(M, mods, scenes, actors)
+            for k in ("a2m", "m2m", "m2a", "a2a"):
+                err = float(np.abs(out[k] - golden[k]).max())
+                assert err <= FTOL, (impl, k, err)
+    finally:
+        ops.set_att_pairs_impl("ws")
+    # (1), (2) on the A2A pair set of the fixture (ragged: 5 scenes, several pairs per target)
+    att = mods["a2a"].att[0]
+    ctrs = [s["ctrs"].cuda() for s in scenes]
+    idcs, n = [], 0
+    for c in ctrs:
+        idcs.append(torch.arange(n, n + len(c), device="cuda"))
+        n += len(c)
+    with torch.no_grad():
+        ps = M.build_pairs(idcs, ctrs, idcs, ctrs, M.config["actor2actor_dist"])
+        P = ps.count()
+        assert P > 64
+        x = torch.from_numpy(golden["m2a"]).cuda()
+        c0 = att.ctx[0]
+        U = ops.agg_mlp(n, [ops.RelSpec(x, ops.packed(att.query.linear.weight))], M.L.F_GN1 | M.L.F_RELU1 | M.L.F_GEMM2,
+                        gn1=M._gn(att.query.norm), wp2=ops.packed(c0.linear.weight, 128, 128))
+        V = ops.agg_mlp(n, [ops.RelSpec(x, ops.packed(c0.linear.weight, 256, 128))], 0)
+        args = (ps, att.dist[0].weight, att.dist[0].bias, ops.packed(att.dist[2].linear.weight), M._gn(att.dist[2].norm),
+                ops.packed(c0.linear.weight, 0, 128), U, V, M._gn(c0.norm))
+        ops.set_att_pairs_impl("stream")
+        try:
+            m_ref = ops.att_pairs(*args)[:P].cpu().numpy()
+        finally:
+            ops.set_att_pairs_impl("ws")
+        m_ws = ops.att_pairs(*args)[:P].cpu().numpy()
+        assert float(np.abs(m_ws - m_ref).max()) <= 2e-5 * max(1.0, float(np.abs(m_ref).max()))
+        canary = torch.full((ps.cap, 128), 7777.0, device="cuda")
+        m_seg = ops.att_pairs(*args, m=canary, seg=16).cpu().numpy()
+        hi = ps.hi[:P].cpu().numpy()
+        first = np.ones(P, bool)
+        first[1:] = (hi[1:] != hi[:-1]) | (np.arange(1, P) % 16 == 0)
+        starts = np.flatnonzero(first)
+        want = np.add.reduceat(m_ws.astype(np.float64), starts, axis=0)
+        assert float(np.abs(m_seg[starts] - want).max()) <= 1e-4 * max(1.0, float(np.abs(want).max()))
+        untouched = np.ones(ps.cap, bool)
+        untouched[starts] = False
+        assert (m_seg[untouched] == 7777.0).all()
 
 
 def test_net_forward_graph_cache(golden, ref_state_names, hip):

@@ -126,10 +126,10 @@ def test_unknown_flag_bits_and_laneconv_arguments(lib):
         assert l.lgcn_agg_mlp(C.byref(p), None) == EINVAL
     m, c = C.c_int32(), C.c_int32()
     assert l.lgcn_lc_config(mod.MMA_F32, 0, C.byref(m), C.byref(c)) == ESHAPE          # exact f32: lgcn_agg_mlp path
-    assert l.lgcn_lc_config(mod.MMA_F16X2, 2, C.byref(m), C.byref(c)) == EINVAL
+    assert l.lgcn_lc_config(mod.MMA_F16X2, 3, C.byref(m), C.byref(c)) == EINVAL
     geoms = {}
     for mma in (mod.MMA_BF16X3, mod.MMA_F16X2, mod.MMA_BF16):
-        for v in (0, 1):
+        for v in (0, 1, 2):
             assert l.lgcn_lc_config(mma, v, C.byref(m), C.byref(c)) == 0
             assert m.value % 16 == 0 and c.value >= m.value
             geoms[(mma, v)] = (m.value, c.value)
@@ -145,6 +145,16 @@ def test_unknown_flag_bits_and_laneconv_arguments(lib):
     assert l.lgcn_lc_plan_build(C.c_void_p(256), C.c_void_p(256), 100, 14, M_, cap, 2, gs, C.c_void_p(260), None) == EALIGN
     bad = (C.c_int32 * 3)(0, 8, 14)                                                     # groups must end at n_units
     assert l.lgcn_lc_plan_build(C.c_void_p(256), C.c_void_p(256), 100, 14, M_, cap, 2, bad, C.c_void_p(256), None) == EINVAL
+    # the weight-stationary pair kernel: split-precision modes only, seg in {0, 16}; RANGE16 relations likewise
+    pa = [C.c_void_p(256)] * 5 + [64] + [C.c_void_p(256)] * 10 + [1e-5]
+    assert l.lgcn_att_pairs_ws(*pa, mod.MMA_F32, 0, C.c_void_p(256), None) == ESHAPE
+    assert l.lgcn_att_pairs_ws(*pa, mod.MMA_F16X2, 8, C.c_void_p(256), None) == EINVAL
+    assert l.lgcn_att_pairs_ws(*pa, mod.MMA_F16X2, 16, C.c_void_p(260), None) == EALIGN
+    pa[5] = 0
+    assert l.lgcn_att_pairs_ws(*pa, mod.MMA_F16X2, 16, C.c_void_p(256), None) == 0      # no capacity: nothing to do
+    p.flags, p.mma = 0, mod.MMA_F32
+    p.rel[0].mode = mod.REL_RANGE16
+    assert l.lgcn_agg_mlp(C.byref(p), None) == ESHAPE
     q = mod.LaneConv()
     assert l.lgcn_laneconv_fwd(None, None) == EINVAL
     q.mma = mod.MMA_F32
