@@ -121,18 +121,18 @@ typedef struct {
 int lgcn_pairs_build_multi(const lgcn_pairs_job_t *jobs, int n_jobs, void *stream);
 
 /*
- * The whole integer stage of a forward in THREE launches (count | scan | fill) instead of the twelve of
+ * The whole integer stage of a forward in FOUR launches (count | scan | fill | sort) instead of the twelve of
  * lgcn_graph_gather + lgcn_csr_build + lgcn_pairs_build_multi; bit-identical outputs.
  *   idx_local [n_elem], seg_off / seg_base [n_seg]: as lgcn_graph_gather (reference lanegcn.py:191-208); relation r's
  *     destination indices are elements u_off[r] .. u_off[r] + n_edges[r] of the gathered array, its sources start at
  *     v_off[r] (the global indices are formed on the fly and not written out).
  *   rowptr [lgcn_csr_rowptr_elems], col [sum n_edges]: the plan of lgcn_csr_build.
- *   cnt   : lgcn_csr_rowptr_elems(n_nodes, n_rel) 64-bit words, 8-byte aligned.  MUST BE ALL ZERO on entry; the
- *           launches leave it all zero again, so one buffer per stream serves every call without a zeroing launch.
+ *   cnt   : lgcn_index_cnt_words(n_nodes, n_rel) 64-bit words, 8-byte aligned.  MUST BE ALL ZERO on entry; the
+ *           launches leave it all zero again, so a buffer serves call after call without a zeroing launch (one
+ *           buffer per forward that can be in flight).
  *   uv    : int32 workspace, lgcn_index_uv_elems(sum n_edges) elements.
  *   jobs  : up to four pair searches (HOST array, as lgcn_pairs_build_multi); n_jobs may be 0.
- * Limits of this entry point (LGCN_ESHAPE beyond them; use the separate calls there): sum n_edges < 2^21,
- * lgcn_csr_rowptr_elems <= 2^22.
+ * Limit of this entry point (LGCN_ESHAPE beyond it; use the separate calls there): lgcn_csr_rowptr_elems <= 2^22.
  */
 typedef struct {
     const int64_t *idx_local; int64_t n_elem;
@@ -145,6 +145,7 @@ typedef struct {
     const lgcn_pairs_job_t *jobs; int32_t n_jobs, pad_;
 } lgcn_index_t;
 int64_t lgcn_index_uv_elems(int64_t n_edges);
+int64_t lgcn_index_cnt_words(int64_t n_nodes, int n_rel);
 int lgcn_index_build(const lgcn_index_t *p_host, void *stream);
 
 /* int32 -> int64 widening of the first *n (device count, clamped to cap)

@@ -115,6 +115,7 @@ SIGNATURES = {
     "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
     "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
     "lgcn_index_uv_elems": (C.c_int64, [_L]),
+    "lgcn_index_cnt_words": (C.c_int64, [_L, _I]),
     "lgcn_index_build": (C.c_int, [_P, _P]),
     "lgcn_att_pairs_ws": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _I, _P, _P]),
 }

@@ -222,14 +222,17 @@ void k_att_pairs_ws(const PairParams p, const int seg) {
     uint4 w1[NP][4], w2[NP][4];
     {
         const uint4 *B1 = reinterpret_cast<const uint4 *>(p.wpd2), *B2 = reinterpret_cast<const uint4 *>(p.wpc0e);
+        // W_d2 first: the first GEMM waits for it alone, W_c0e lands under that GEMM
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int o = ((((pl * 4 + (wave >> 1)) * 4 + ks) * 2 + (wave & 1)) << 6) + lane;
-                w1[pl][ks] = B1[o];
-                w2[pl][ks] = B2[o];
-            }
+            for (int ks = 0; ks < 4; ++ks)
+                w1[pl][ks] = B1[((((pl * 4 + (wave >> 1)) * 4 + ks) * 2 + (wave & 1)) << 6) + lane];
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                w2[pl][ks] = B2[((((pl * 4 + (wave >> 1)) * 4 + ks) * 2 + (wave & 1)) << 6) + lane];
     }
     if (tid < 2 * kC) s_par[tid] = p.wd0[tid];
     else if (tid < 3 * kC) s_par[tid] = p.bd0[tid - 2 * kC];

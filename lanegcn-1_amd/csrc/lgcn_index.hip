@@ -336,22 +336,21 @@ __global__ __launch_bounds__(1024) void k_pairs_scan_bases(const PairsJobs jobs)
 }
 
 // ------------------------------------------------- fused index pipeline -----
-// lgcn_index_build: graph_gather + CSR plan + up to four pair searches in THREE launches (count | scan | fill)
+// lgcn_index_build: graph_gather + CSR plan + up to four pair searches in FOUR launches (count | scan | fill | sort)
 // instead of twelve.  At S2 every one of those launches is a few microseconds of work behind a launch boundary
 // of the same size; what the twelve cost is their number.
 //   * graph_gather is folded into the edge pass: an edge thread turns its two local indices into global ones
 //     (binary search of the segment table) and keeps them as an int32 pair for the fill pass.
-//   * the per-key counter is a 64-bit word with three 21-bit fields: [0,21) edges counted (pass 1), [21,42) slots
-//     handed out, [42,63) slots written (pass 3).  The thread that completes a key's last slot sorts the key's
-//     entries (ascending source, as k_csr_sort_rows) and writes the word back to ZERO: the counters must be zero
-//     on entry and are zero again when the launch has finished -- no zeroing launch, no separate cursor, no sort
-//     launch.
-//   * the scan of the 145 k keys is one launch of independent 4096-key tiles: tile b first sums the counters in
-//     front of it (they are L2-resident), then scans its own.
-//   * the pair searches' count / scan / fill bodies ride in the same launches as extra workgroups.
-constexpr int kIdxBits = 21;
-constexpr unsigned long long kIdxMask = (1ull << kIdxBits) - 1ull;
+//   * the per-key counter word serves the count pass (low half: edges of the key) AND the fill pass (high half: slots
+//     handed out); the sort pass, which puts each key's entries in canonical (ascending source) order, writes it
+//     back to ZERO.  The counters must be zero on entry and are zero again on completion: no zeroing launch and no
+//     separate cursor array.  (Sorting a key from the thread that fills its last slot -- one launch fewer -- was
+//     measured 8 x slower: the release/acquire pair it needs is a write-back + invalidate of an XCD's L2 per wave.)
+//   * the count pass also adds up the keys of every 4096-key scan tile (LDS histogram per workgroup, one global
+//     atomic per touched tile), so the scan is ONE launch of independent tiles: tile b adds the totals in front of it.
+//   * the pair searches' count / scan / fill bodies ride in the first three launches as extra workgroups.
 constexpr int kIdxScanTile = 4096;      // 1024 threads x 4 keys
+constexpr int kIdxMaxTiles = 1024;      // n_keys1 <= 2^22
 
 struct IndexParams {
     const int64_t *idx_local, *seg_off, *seg_base;
@@ -359,7 +358,8 @@ struct IndexParams {
     int64_t u_off[LGCN_MAX_REL], v_off[LGCN_MAX_REL];
     int64_t start[LGCN_MAX_REL + 1];          // prefix of the relations' edge counts
     int64_t n_nodes, n_keys1;                 // keys + 1
-    unsigned long long *cnt;                  // [n_keys1], zero on entry and on completion
+    unsigned long long *cnt;                  // [n_keys1 + kIdxMaxTiles], zero on entry and on completion:
+                                              // per key (edges | slots handed out << 32), then the scan tiles' totals
     int32_t *uv;                              // [2 * total] global (u, v) of every edge; u = -1: dropped
     int32_t *rowptr, *col;
     int edge_blocks, scan_blocks, n_jobs;
@@ -378,6 +378,7 @@ __device__ __forceinline__ int64_t to_global(const IndexParams &p, int64_t i) {
 
 template <int PASS>     // 0: count, 1: fill
 __global__ __launch_bounds__(256) void k_index_edges(const IndexParams p) {
+    __shared__ int s_tile[kIdxMaxTiles];
     const int bid = blockIdx.x;
     if (bid >= p.edge_blocks) {               // pair-search workgroups
         const int b = bid - p.edge_blocks;
@@ -387,6 +388,10 @@ __global__ __launch_bounds__(256) void k_index_edges(const IndexParams p) {
         pairs_rows_body<PASS>(j.agt, j.agt_off, j.ctx, j.ctx_off, j.n_scenes, j.n_agt, j.th, j.rp(), j.rp(), j.hi_base(),
                               j.wi_base(), j.hi, j.wi, j.cap, j.legacy, j.rowptr_q, b - p.job_blocks[jn]);
         return;
+    }
+    if (PASS == 0) {
+        for (int i = threadIdx.x; i < p.scan_blocks; i += blockDim.x) s_tile[i] = 0;
+        __syncthreads();
     }
     const int64_t total = p.start[p.n_rel];
     for (int64_t e = (int64_t)bid * blockDim.x + threadIdx.x; e < total; e += (int64_t)p.edge_blocks * blockDim.x) {
@@ -398,29 +403,23 @@ __global__ __launch_bounds__(256) void k_index_edges(const IndexParams p) {
             const bool ok = u >= 0 && u < p.n_nodes && v >= 0 && v < p.n_nodes;     // never index out of bounds
             p.uv[2 * e] = ok ? (int32_t)u : -1;
             p.uv[2 * e + 1] = (int32_t)v;
-            if (ok) atomicAdd(&p.cnt[csr_key(u, r, p.n_rel)], 1ull);
+            if (ok) {
+                const int64_t k = csr_key(u, r, p.n_rel);
+                atomicAdd(&p.cnt[k], 1ull);
+                atomicAdd(&s_tile[k / kIdxScanTile], 1);
+            }
         } else {
             const int u = p.uv[2 * e], v = p.uv[2 * e + 1];
             if (u < 0) continue;
             const int64_t k = csr_key(u, r, p.n_rel);
-            const int base = p.rowptr[k];
-            const unsigned long long a = atomicAdd(&p.cnt[k], 1ull << kIdxBits);
-            p.col[base + (int)((a >> kIdxBits) & kIdxMask)] = v;
-            __threadfence();                  // the slot is visible before it is counted as written
-            const unsigned long long d = atomicAdd(&p.cnt[k], 1ull << (2 * kIdxBits));
-            const int n = (int)(d & kIdxMask);
-            if ((int)((d >> (2 * kIdxBits)) & kIdxMask) + 1 == n) {     // last slot of the key: canonical order, reset
-                __threadfence();
-                volatile int32_t *c = p.col + base;
-                for (int i = 1; i < n; ++i) {
-                    const int x = c[i];
-                    int q = i - 1;
-                    while (q >= 0 && c[q] > x) { c[q + 1] = c[q]; --q; }
-                    c[q + 1] = x;
-                }
-                p.cnt[k] = 0ull;
-            }
+            const unsigned long long a = atomicAdd(&p.cnt[k], 1ull << 32);
+            p.col[p.rowptr[k] + (int)(a >> 32)] = v;
         }
+    }
+    if (PASS == 0) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < p.scan_blocks; i += blockDim.x)
+            if (s_tile[i] != 0) atomicAdd(&p.cnt[p.n_keys1 + i], (unsigned long long)s_tile[i]);
     }
 }
 
@@ -434,17 +433,15 @@ __global__ __launch_bounds__(1024) void k_index_scan(const IndexParams p) {
         if (j.n_agt == 0 && threadIdx.x == 0) j.rowptr_q[0] = 0;
         return;
     }
-    // counters in front of this tile
-    const int64_t t0 = (int64_t)bid * kIdxScanTile;
-    int part = 0;
-    for (int64_t i = threadIdx.x; i < t0; i += 1024) part += (int)(p.cnt[i] & kIdxMask);
+    // keys in front of this tile: the totals of the tiles in front of it (<= 1024: one per thread)
+    const int part = (int)threadIdx.x < bid ? (int)p.cnt[p.n_keys1 + threadIdx.x] : 0;
     int before;
     block_exclusive_scan<1024>(part, &before, lds);
-    const int64_t b = t0 + 4 * (int64_t)threadIdx.x;
+    const int64_t b = (int64_t)bid * kIdxScanTile + 4 * (int64_t)threadIdx.x;
     int v[4], sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        v[k] = b + k < p.n_keys1 ? (int)(p.cnt[b + k] & kIdxMask) : 0;
+        v[k] = b + k < p.n_keys1 ? (int)(p.cnt[b + k] & 0xffffffffull) : 0;
         sum += v[k];
     }
     int tile_total;
@@ -453,6 +450,24 @@ __global__ __launch_bounds__(1024) void k_index_scan(const IndexParams p) {
     for (int k = 0; k < 4; ++k) {
         if (b + k < p.n_keys1) p.rowptr[b + k] = off;
         off += v[k];
+    }
+}
+
+// canonical order inside each key (as k_csr_sort_rows) + the counters back to zero
+__global__ __launch_bounds__(256) void k_index_sort(const IndexParams p) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < kIdxMaxTiles) p.cnt[p.n_keys1 + k] = 0ull;
+    if (k >= p.n_keys1) return;
+    const unsigned long long w = p.cnt[k];
+    if (w == 0ull) return;
+    p.cnt[k] = 0ull;
+    const int n = (int)(w & 0xffffffffull);
+    int32_t *c = p.col + p.rowptr[k];
+    for (int i = 1; i < n; ++i) {
+        const int x = c[i];
+        int q = i - 1;
+        while (q >= 0 && c[q] > x) { c[q + 1] = c[q]; --q; }
+        c[q + 1] = x;
     }
 }
 
@@ -613,6 +628,11 @@ int lgcn_pairs_build(const float *agt_ctrs, const int32_t *agt_off, const float 
 
 int64_t lgcn_index_uv_elems(int64_t n_edges) { return n_edges < 0 ? (int64_t)LGCN_EINVAL : 2 * n_edges; }
 
+int64_t lgcn_index_cnt_words(int64_t n_nodes, int n_rel) {
+    const int64_t k = lgcn_csr_rowptr_elems(n_nodes, n_rel);
+    return k < 0 ? k : k + kIdxMaxTiles;
+}
+
 int lgcn_index_build(const lgcn_index_t *ph, void *stream) {
     LGCN_CHECK_PTR(ph);
     const lgcn_index_t &q = *ph;
@@ -633,10 +653,9 @@ int lgcn_index_build(const lgcn_index_t *ph, void *stream) {
     }
     for (int r = q.n_rel; r < LGCN_MAX_REL; ++r) { p.u_off[r] = p.v_off[r] = 0; p.start[r + 1] = p.start[q.n_rel]; }
     const int64_t total = p.start[q.n_rel];
-    // a key's three counter fields hold 21 bits each: no key can exceed the total edge count
-    if (total > (int64_t)kIdxMask || q.n_nodes > 0x7fffffff) return LGCN_ESHAPE;
+    if (total > 0x7fffffff || q.n_nodes > 0x7fffffff) return LGCN_ESHAPE;
     const int64_t nk1 = lgcn_csr_rowptr_elems(q.n_nodes, q.n_rel);
-    if (nk1 > (int64_t)1 << 22) return LGCN_ESHAPE;      // the one-launch scan re-reads the counters in front of a tile
+    if (nk1 > (int64_t)kIdxScanTile * kIdxMaxTiles) return LGCN_ESHAPE;      // one scan launch: <= 1024 tiles of 4096 keys
     if (total > 0) {
         LGCN_CHECK_PTR(q.idx_local); LGCN_CHECK_PTR(q.seg_off); LGCN_CHECK_PTR(q.seg_base);
         LGCN_CHECK_PTR(q.col); LGCN_CHECK_PTR(q.uv);
@@ -672,6 +691,7 @@ int lgcn_index_build(const lgcn_index_t *ph, void *stream) {
     if (g13 > 0) hipLaunchKernelGGL((k_index_edges<0>), dim3(g13), dim3(256), 0, st, p);
     hipLaunchKernelGGL(k_index_scan, dim3((unsigned)(p.scan_blocks + q.n_jobs)), dim3(1024), 0, st, p);
     if (g13 > 0) hipLaunchKernelGGL((k_index_edges<1>), dim3(g13), dim3(256), 0, st, p);
+    if (total > 0) hipLaunchKernelGGL(k_index_sort, dim3((unsigned)((nk1 + 255) / 256)), dim3(256), 0, st, p);
     return launch_status();
 }
 

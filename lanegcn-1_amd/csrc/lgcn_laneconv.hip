@@ -84,6 +84,7 @@ constexpr int kLcHash = 1024;
 __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
     __shared__ int hkey[kLcHash], hrow[kLcHash], hval[kLcHash];
     __shared__ int s_w[4], s_cnt[4], s_ul[16];
+    __shared__ int s_pre[3 * kLcUnits * 256];      // [unit of the group][e0 | degree | source][row]: read back by the same thread
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / p.n_groups, g = blockIdx.x % p.n_groups;
     const int u_begin = p.gstart[g], u_end = p.gstart[g + 1];
@@ -120,16 +121,45 @@ __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
     clear();
     __syncthreads();
 
+    // this row's (first edge, degree, single source) under every unit of the group, fetched up front: two global round
+    // trips per workgroup instead of two per unit (the unit loop below is a chain of barriers: latency-bound)
+    {
+        int e0s[kLcUnits], degs[kLcUnits];
+#pragma unroll
+        for (int j = 0; j < kLcUnits; ++j) {
+            const int u = u_begin + j;
+            e0s[j] = 0; degs[j] = 0;
+            if (row_ok && u < u_end && u > 0) {
+                const int64_t k = ((n >> 4) * p.n_rel + (u - 1)) * 16 + (n & 15);
+                e0s[j] = p.rowptr[k];
+                degs[j] = p.rowptr[k + 1];
+            }
+        }
+        int keys[kLcUnits];
+#pragma unroll
+        for (int j = 0; j < kLcUnits; ++j) {
+            degs[j] -= e0s[j];
+            keys[j] = -1;
+            if (degs[j] == 1) keys[j] = p.col[e0s[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < kLcUnits; ++j) {
+            s_pre[(3 * j) * 256 + tid] = e0s[j];
+            s_pre[(3 * j + 1) * 256 + tid] = degs[j];
+            s_pre[(3 * j + 2) * 256 + tid] = keys[j];
+        }
+    }
+
     int cur_u0 = u_begin, n_src = 0, n_live = 0;      // workgroup-uniform
     for (int u = u_begin; u < u_end; ++u) {
         int deg = 0, e0 = 0, key = -1;
         if (row_ok) {
             if (u == 0) { deg = 1; key = (int)n; }
             else {
-                const int64_t k = ((n >> 4) * p.n_rel + (u - 1)) * 16 + (n & 15);
-                e0 = p.rowptr[k];
-                deg = p.rowptr[k + 1] - e0;
-                if (deg == 1) key = p.col[e0];
+                const int j = u - u_begin;
+                e0 = s_pre[(3 * j) * 256 + tid];
+                deg = s_pre[(3 * j + 1) * 256 + tid];
+                key = s_pre[(3 * j + 2) * 256 + tid];
             }
         }
         {

@@ -183,8 +183,22 @@ class HotPathEngine:
         # scenes/s) and a loss with four graphs in flight (61 k vs 90 k) -> off by default.
         self.branches = branches
         self._side = None
-        # the integer stage as lgcn_index_build (3 launches) instead of 12; False: the separate entry points
+        # the integer stage as lgcn_index_build (4 launches) instead of 12; False: the separate entry points
         self.fused_index = os.environ.get("LGCN_INDEX", "fused") == "fused"
+        self._cnt_capture = None      # counter buffer of the forward being captured (capture())
+        self._cnt_keep = []           # ... and of every graph captured so far (they live as long as the engine)
+
+    def _counters(self, fb: FlatBatch) -> torch.Tensor:
+        """Key counters of lgcn_index_build (zero before, zero after).  A captured forward owns a buffer of its own
+        (capture() sets it); eager forwards share one per FlatBatch -- do not run two eager forwards of the SAME
+        FlatBatch concurrently on different streams."""
+        if self._cnt_capture is not None:
+            return self._cnt_capture
+        cnt = fb.__dict__.get("_idx_cnt")
+        if cnt is None:
+            cnt = ops.index_counters(fb.n_nodes, len(fb.rel_slices), fb.node_ctrs.device)
+            fb.__dict__["_idx_cnt"] = cnt
+        return cnt
 
     @torch.no_grad()
     def forward(self, fb: FlatBatch, actors: torch.Tensor, stages: bool = False,
@@ -214,9 +228,9 @@ class HotPathEngine:
         if side is not None:
             side.wait_stream(main)
         if side is None and self.fused_index and ops.index_fused_ok(fb.n_nodes, len(fb.rel_slices), sum(fb.n_edges)):
-            # graph_gather (lanegcn.py:171-209) + CSR plan + the three pair searches: three launches in all
+            # graph_gather (lanegcn.py:171-209) + CSR plan + the three pair searches: four launches in all
             plan, pairs = ops.index_build(fb.idx_local, fb.seg_off, fb.seg_base, fb.rel_slices, fb.n_nodes, searches,
-                                          self.legacy_offsets, bufs=bufs)
+                                          self.legacy_offsets, bufs=bufs, cnt=self._counters(fb))
         else:
             with torch.cuda.stream(side if side is not None else main):
                 pairs = ops.pairs_build_multi(searches, self.legacy_offsets, bufs=bufs)   # three sets, three launches
@@ -283,6 +297,13 @@ class HotPathEngine:
             searches = ((fb.node_ctrs, fb.node_off, fb.actor_ctrs, fb.actor_off, cfg["actor2map_dist"], fb.cap_a2m),
                         (fb.actor_ctrs, fb.actor_off, fb.node_ctrs, fb.node_off, cfg["map2actor_dist"], fb.cap_a2m),
                         (fb.actor_ctrs, fb.actor_off, fb.actor_ctrs, fb.actor_off, cfg["actor2actor_dist"], fb.cap_a2a))
+            if self.fused_index and ops.index_fused_ok(fb.n_nodes, len(fb.rel_slices), sum(fb.n_edges)):
+                cnt = st.get("_cnt")             # the stage's own counters (its captured graph is replayed alone)
+                if cnt is None:
+                    cnt = st["_cnt"] = ops.index_counters(fb.n_nodes, len(fb.rel_slices), fb.node_ctrs.device)
+                st["plan"], st["pairs"] = ops.index_build(fb.idx_local, fb.seg_off, fb.seg_base, fb.rel_slices, fb.n_nodes,
+                                                          searches, self.legacy_offsets, cnt=cnt)
+                return
             st["pairs"] = ops.pairs_build_multi(searches, self.legacy_offsets)
             g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
             st["plan"] = ops.csr_build([g64[a:b] for (a, b), _ in fb.rel_slices],
@@ -325,10 +346,28 @@ class HotPathEngine:
                 self.forward(fb, actors, **fwd_kw)   # also fills the weight-pack caches outside the capture
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = self.forward(fb, actors, **fwd_kw)
+        with self.own_counters(fb):
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self.forward(fb, actors, **fwd_kw)
         return graph, out
+
+    def own_counters(self, fb: FlatBatch):
+        """Context: forwards inside it use a fresh, zeroed counter buffer that stays alive with the engine -- for a
+        forward that is being captured (several captured forwards may replay concurrently)."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            cnt = ops.index_counters(fb.n_nodes, len(fb.rel_slices), fb.node_ctrs.device)
+            torch.cuda.synchronize()         # zeroed before anything captured can run
+            self._cnt_keep.append(cnt)
+            prev, self._cnt_capture = self._cnt_capture, cnt
+            try:
+                yield
+            finally:
+                self._cnt_capture = prev
+        return cm()
 
 
 class FullNetEngine:
@@ -384,9 +423,10 @@ class FullNetEngine:
                     self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
+            with self.hot.own_counters(fb):
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    out = self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
         finally:
             torch.backends.cudnn.benchmark = prev
         return graph, out

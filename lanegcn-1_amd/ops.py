@@ -306,36 +306,25 @@ def _pairs_jobs(searches, legacy_offsets, bufs):
     return jobs, out, keep
 
 
-# Counter words of lgcn_index_build: zero on entry, zero again on completion.  One buffer per (device, stream, size),
-# created zeroed on first use -- make that first use an eager call (a buffer first created under stream capture is
-# zeroed by a captured fill, i.e. on every replay: correct, but a launch the design is there to save).
-_index_cnt = {}
-
-
-def index_counters(n_words: int, device) -> torch.Tensor:
-    key = (torch.device(device), torch.cuda.current_stream().cuda_stream, n_words)
-    buf = _index_cnt.get(key)
-    if buf is None:
-        buf = torch.zeros(n_words, dtype=torch.int64, device=device)
-        _index_cnt[key] = buf
-    return buf
-
-
-def reset_index_counters():
-    """Drop the cached counter buffers (after a forward that was aborted between the count and the fill launches)."""
-    _index_cnt.clear()
+def index_counters(n_nodes: int, n_rel: int, device) -> torch.Tensor:
+    """A zeroed counter buffer for index_build (lgcn_index_build needs it all zero and leaves it all zero): keep ONE
+    per forward that can be in flight -- two launches sharing a buffer concurrently corrupt each other's counts."""
+    lib = L.load()
+    return torch.zeros(lib.lgcn_index_cnt_words(n_nodes, n_rel), dtype=torch.int64, device=device)
 
 
 def index_fused_ok(n_nodes: int, n_rel: int, n_edges_total: int) -> bool:
     """Whether lgcn_index_build takes this size (else: graph_gather_indices + csr_build + pairs_build_multi)."""
     lib = L.load()
-    return n_edges_total < (1 << 21) and lib.lgcn_csr_rowptr_elems(n_nodes, n_rel) <= (1 << 22)
+    return n_edges_total < (1 << 31) and lib.lgcn_csr_rowptr_elems(n_nodes, n_rel) <= (1 << 22)
 
 
 def index_build(idx_local: torch.Tensor, seg_off: torch.Tensor, seg_base: torch.Tensor, rel_slices, n_nodes: int,
-                searches=(), legacy_offsets: bool = True, bufs=None):
-    """graph_gather + CSR plan + the pair searches in three launches (lgcn_index_build).  rel_slices: per relation
-    ((u_begin, u_end), (v_begin, v_end)) element ranges of idx_local.  Returns (LanePlan, [PairSet])."""
+                searches=(), legacy_offsets: bool = True, bufs=None, cnt: Optional[torch.Tensor] = None):
+    """graph_gather + CSR plan + the pair searches in four launches (lgcn_index_build).  rel_slices: per relation
+    ((u_begin, u_end), (v_begin, v_end)) element ranges of idx_local.  cnt: index_counters() buffer owned by the caller
+    (all zero; comes back all zero); None: a fresh one per call (one extra fill launch).
+    Returns (LanePlan, [PairSet])."""
     lib = L.load()
     idx_local = _dev(idx_local, torch.int64, "idx_local")
     seg_off = _dev(seg_off, torch.int64, "seg_off")
@@ -349,7 +338,10 @@ def index_build(idx_local: torch.Tensor, seg_off: torch.Tensor, seg_base: torch.
     rowptr = torch.empty(nk1, dtype=torch.int32, device=dev)
     col = torch.empty(max(sum(ne), 1), dtype=torch.int32, device=dev)
     uv = torch.empty(max(2 * sum(ne), 2), dtype=torch.int32, device=dev)
-    cnt = index_counters(nk1, dev)
+    if cnt is None:
+        cnt = index_counters(n_nodes, n_rel, dev)
+    elif cnt.numel() < lib.lgcn_index_cnt_words(n_nodes, n_rel) or cnt.dtype != torch.int64 or cnt.device != dev:
+        raise L.LgcnError("index_build: counter buffer of the wrong size / type / device")
     jobs, pairs, keep = _pairs_jobs(searches, legacy_offsets, bufs)
     p = L.Index()
     p.idx_local, p.n_elem = idx_local.data_ptr(), idx_local.numel()
@@ -362,7 +354,9 @@ def index_build(idx_local: torch.Tensor, seg_off: torch.Tensor, seg_base: torch.
     p.rowptr, p.col, p.cnt, p.uv = rowptr.data_ptr(), col.data_ptr(), cnt.data_ptr(), uv.data_ptr()
     p.jobs, p.n_jobs = C.cast(jobs, C.c_void_p).value if len(searches) else 0, len(searches)
     L.check(lib.lgcn_index_build(C.byref(p), _stream()), "lgcn_index_build")
-    return LanePlan(rowptr, col, n_rel, n_nodes, ne), pairs
+    plan = LanePlan(rowptr, col, n_rel, n_nodes, ne)
+    plan.__dict__["_idx_keep"] = (cnt, uv, keep)       # alive until the plan is dropped (the launches are asynchronous)
+    return plan, pairs
 
 
 # ------------------------------------------------------------------ weight packing

@@ -544,8 +544,10 @@ def test_fused_index_stage_is_bit_identical(hip):
                     (fb.actor_ctrs, fb.actor_off, fb.actor_ctrs, fb.actor_off, cfg["actor2actor_dist"], fb.cap_a2a))
         want_pairs = ops.pairs_build_multi(searches, True)
         assert ops.index_fused_ok(fb.n_nodes, len(fb.rel_slices), sum(fb.n_edges))
+        cnt = ops.index_counters(fb.n_nodes, len(fb.rel_slices), fb.node_ctrs.device)
         for rep in range(2):
-            plan, pairs = ops.index_build(fb.idx_local, fb.seg_off, fb.seg_base, fb.rel_slices, fb.n_nodes, searches, True)
+            plan, pairs = ops.index_build(fb.idx_local, fb.seg_off, fb.seg_base, fb.rel_slices, fb.n_nodes, searches, True,
+                                          cnt=cnt)
             assert torch.equal(plan.rowptr, want.rowptr) and torch.equal(plan.col, want.col), (seed, rep)
             assert plan.n_edges == want.n_edges
             for got, ref in zip(pairs, want_pairs):
@@ -553,7 +555,6 @@ def test_fused_index_stage_is_bit_identical(hip):
                 assert got.count() == P
                 assert torch.equal(got.hi[:P], ref.hi[:P]) and torch.equal(got.wi[:P], ref.wi[:P])
                 assert torch.equal(got.rowptr, ref.rowptr)
-            cnt = ops.index_counters(plan.rowptr.numel(), plan.rowptr.device)
             assert int(cnt.abs().sum()) == 0
     # a multigraph given as ONE segment per run (local = global), no pair job
     rng = np.random.default_rng(3)
