@@ -1,5 +1,5 @@
 """Per-kernel summary of a rocprofv3 --kernel-trace database (rocpd sqlite): calls, average / total duration, and
-the average number of kernels in flight.  Usage: python tools/trace_summary.py results.db [last_fraction]"""
+the average number of kernels in flight.  Usage: python tools/trace_summary.py results.db [last_fraction [stats.csv]]"""
 import collections
 import sqlite3
 import sys
@@ -37,6 +37,16 @@ def main():
     print("%-22s %7s %9s %10s %6s" % ("kernel", "calls", "avg us", "total us", "%"))
     for k, v in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         print("%-22s %7d %9.2f %10.1f %6.1f" % (k, len(v), np.mean(v), sum(v), 100 * sum(v) / tot))
+    if len(sys.argv) > 3:      # per-kernel stats over the WHOLE run (full names), the layout of rocprofv3 --stats
+        full = collections.defaultdict(list)
+        for n, s, e, q in c.execute("select s.kernel_name, d.start, d.end, d.queue_id from %s d join %s s on d.kernel_id = s.id" % (kd, ks)):
+            full[n].append(e - s)
+        allt = sum(sum(v) for v in full.values())
+        with open(sys.argv[3], "w") as f:
+            f.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n')
+            for n, v in sorted(full.items(), key=lambda kv: -sum(kv[1])):
+                v = np.asarray(v, np.float64)
+                f.write('"%s",%d,%d,%.6f,%.4f,%d,%d,%.6f\n' % (n, len(v), v.sum(), v.mean(), 100 * v.sum() / allt, v.min(), v.max(), v.std()))
 
 
 if __name__ == "__main__":
