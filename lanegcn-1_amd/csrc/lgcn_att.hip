@@ -187,6 +187,10 @@ __global__ __launch_bounds__(256) void k_att_fused(const AttFusedParams p) {
 }
 
 
+#ifdef LGCN_STAMPS
+__device__ unsigned long long *g_att_stamps = nullptr;     // diagnostic build only (tools/stamps_att.py)
+#endif
+
 // --------------------------------------------------- weight-stationary pair MLP -----
 // lgcn_att_pairs_ws: the per-pair MLP of Att.forward (lanegcn.py:691-700) with both 128 x 128 weights held in
 // REGISTERS for the whole launch.  k_att_pairs_bf streams 128 KB of weight fragments L2 -> VGPR per 32-pair tile
@@ -206,10 +210,19 @@ template <int F>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(F == 0 ? 2 : 4)))
 void k_att_pairs_ws(const PairParams p, const int seg) {
     constexpr int RB = 4, ROWS = 64, NP = Fmt<F>::NP;
+#ifdef LGCN_STAMPS
+    unsigned long long *sbuf = (g_att_stamps && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7))
+                                   ? g_att_stamps + ((int64_t)blockIdx.x * 2 + ((threadIdx.x >> 6) == 7)) * 32 : nullptr;
+    int sidx = 0;
+#define AT_STAMP() do { if (sbuf && sidx < 32) sbuf[sidx] = stamp(); ++sidx; } while (0)
+#else
+#define AT_STAMP() do { } while (0)
+#endif
+    AT_STAMP();   // 0 start
     using TL = Tile<RB, F>;
     __shared__ __attribute__((aligned(16))) unsigned char smem[TL::ABUF_BYTES + TL::T_BYTES];
     __shared__ __attribute__((aligned(16))) float s_par[7 * kC];      // wd0 [128][2] | bd0 | gd | btd | gc | btc
-    __shared__ int s_hi[ROWS], s_wi[ROWS];
+    __shared__ __attribute__((aligned(16))) int s_hi[ROWS], s_wi[ROWS];
     uint16_t *A = reinterpret_cast<uint16_t *>(smem);
     float *T = reinterpret_cast<float *>(smem + TL::ABUF_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -218,22 +231,37 @@ void k_att_pairs_ws(const PairParams p, const int seg) {
     const int64_t n_tiles = (P + ROWS - 1) / ROWS;
     if ((int64_t)blockIdx.x >= n_tiles) return;
 
-    // this wave's slices of the two weights: [plane][K-step], channels 16 wave .. + 15
+    const int row = tid >> 3;
+    // pair indices and centre offsets of the first tile (two dependent round trips: requested first, the weight
+    // slices travel beside them); later tiles: requested one tile ahead
+    int64_t tile = blockIdx.x;
+    int hi_c = -1, wi_c = 0;
+    float dx = 0.f, dy = 0.f;
+    auto fetch_idx = [&](int64_t tl, int &h, int &w) {
+        const int64_t pr = tl * ROWS + row;
+        const bool live = tl < n_tiles && pr < P;
+        h = live ? p.hi[pr] : -1;
+        w = live ? p.wi[pr] : 0;
+    };
+    auto fetch_d = [&](int h, int w, float &x, float &y) {
+        x = y = 0.f;
+        if (h >= 0) {
+            const float2 a = reinterpret_cast<const float2 *>(p.agt_ctrs)[h];
+            const float2 c = reinterpret_cast<const float2 *>(p.ctx_ctrs)[w];
+            x = a.x - c.x; y = a.y - c.y;
+        }
+    };
+    fetch_idx(tile, hi_c, wi_c);
+
+    // this wave's slices of the two weights: [plane][K-step], channels 16 wave .. + 15.  W_d2 first: the first GEMM
+    // waits for it alone, W_c0e lands under that GEMM
     uint4 w1[NP][4], w2[NP][4];
-    {
-        const uint4 *B1 = reinterpret_cast<const uint4 *>(p.wpd2), *B2 = reinterpret_cast<const uint4 *>(p.wpc0e);
-        // W_d2 first: the first GEMM waits for it alone, W_c0e lands under that GEMM
+    const uint4 *B1 = reinterpret_cast<const uint4 *>(p.wpd2), *B2 = reinterpret_cast<const uint4 *>(p.wpc0e);
 #pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
+    for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                w1[pl][ks] = B1[((((pl * 4 + (wave >> 1)) * 4 + ks) * 2 + (wave & 1)) << 6) + lane];
-#pragma unroll
-        for (int pl = 0; pl < NP; ++pl)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                w2[pl][ks] = B2[((((pl * 4 + (wave >> 1)) * 4 + ks) * 2 + (wave & 1)) << 6) + lane];
-    }
+        for (int ks = 0; ks < 4; ++ks)
+            w1[pl][ks] = B1[((((pl * 4 + (wave >> 1)) * 4 + ks) * 2 + (wave & 1)) << 6) + lane];
     if (tid < 2 * kC) s_par[tid] = p.wd0[tid];
     else if (tid < 3 * kC) s_par[tid] = p.bd0[tid - 2 * kC];
     else if (tid < 4 * kC) s_par[tid] = p.gd[tid - 3 * kC];
@@ -242,10 +270,15 @@ void k_att_pairs_ws(const PairParams p, const int seg) {
         s_par[5 * kC + tid] = p.gc[tid];
         s_par[6 * kC + tid] = p.btc[tid];
     }
+    fetch_d(hi_c, wi_c, dx, dy);
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            w2[pl][ks] = B2[((((pl * 4 + (wave >> 1)) * 4 + ks) * 2 + (wave & 1)) << 6) + lane];
     const float *l_wd0 = s_par, *l_bd0 = s_par + 2 * kC, *l_gd = s_par + 3 * kC, *l_btd = s_par + 4 * kC;
     const float *l_gc = s_par + 5 * kC, *l_btc = s_par + 6 * kC;
 
-    const int row = tid >> 3;
     const uint16_t *arow = A + (lane & 15) * kLDB + 8 * (lane >> 4);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[RB];
@@ -277,28 +310,9 @@ void k_att_pairs_ws(const PairParams p, const int seg) {
         for (int rb = 0; rb < RB; ++rb)
             *reinterpret_cast<f32x4 *>(T + (16 * rb + (lane & 15)) * kLDA + 16 * wave + 4 * (lane >> 4)) = acc[rb];
     };
-
-    // pair indices and centre offsets of the first tile; later tiles: requested one tile ahead
-    int64_t tile = blockIdx.x;
-    int hi_c = -1, wi_c = 0;
-    float dx = 0.f, dy = 0.f;
-    auto fetch_idx = [&](int64_t tl, int &h, int &w) {
-        const int64_t pr = tl * ROWS + row;
-        const bool live = tl < n_tiles && pr < P;
-        h = live ? p.hi[pr] : -1;
-        w = live ? p.wi[pr] : 0;
-    };
-    auto fetch_d = [&](int h, int w, float &x, float &y) {
-        x = y = 0.f;
-        if (h >= 0) {
-            const float2 a = reinterpret_cast<const float2 *>(p.agt_ctrs)[h];
-            const float2 c = reinterpret_cast<const float2 *>(p.ctx_ctrs)[w];
-            x = a.x - c.x; y = a.y - c.y;
-        }
-    };
-    fetch_idx(tile, hi_c, wi_c);
-    fetch_d(hi_c, wi_c, dx, dy);
-    __syncthreads();          // s_par
+    AT_STAMP();   // 1 requests issued, centres landed
+    lds_barrier();          // s_par
+    AT_STAMP();   // 2
 
     for (; tile < n_tiles; tile += gridDim.x) {
         const int64_t pr0 = tile * ROWS;
@@ -312,11 +326,13 @@ void k_att_pairs_ws(const PairParams p, const int seg) {
         if ((tidv & 7) == 0) { s_hi[rowv] = hi_c; s_wi[rowv] = wi_c; }
         int hi_n, wi_n;
         fetch_idx(tile + gridDim.x, hi_n, wi_n);
-        __syncthreads();
+        lds_barrier();
+        AT_STAMP();   // 3 e0 planes ready
         // ---- e1 = A x W_d2
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[rb] = zero4;
         gemm(w1);
+        AT_STAMP();   // 4 first GEMM issued
         acc_to_tile();
         // U[hi] + V[wi] of this lane's rows / channels: the second GEMM's accumulators start from them
         // (registers: the U rows travel under the row phase, the V rows are requested behind it)
@@ -326,7 +342,8 @@ void k_att_pairs_ws(const PairParams p, const int seg) {
             const int h = s_hi[16 * rb + (lanev & 15)];
             acc[rb] = *reinterpret_cast<const f32x4 *>(p.U + (int64_t)(h < 0 ? 0 : h) * kC + co);
         }
-        __syncthreads();      // T complete; every wave is done reading A
+        lds_barrier();      // T complete; every wave is done reading A
+        AT_STAMP();   // 5
         // ---- e = ReLU(GN_d(e1)) -> A planes
         {
             RowVals r = row_load(T, tidv);
@@ -343,14 +360,19 @@ void k_att_pairs_ws(const PairParams p, const int seg) {
                 const int w = s_hi[r] < 0 ? 0 : s_wi[r];
                 v[rb] = *reinterpret_cast<const f32x4 *>(p.V + (int64_t)w * kC + co);
             }
-            __syncthreads();
+            AT_STAMP();   // 6 row phase done
+            lds_barrier();
+            AT_STAMP();   // 7
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb) acc[rb] = acc[rb] + v[rb];
         }
+        AT_STAMP();   // 8 U + V in the accumulators
         // ---- t = U + V + A x W_c0e
         gemm(w2);
+        AT_STAMP();   // 9
         acc_to_tile();
-        __syncthreads();
+        lds_barrier();
+        AT_STAMP();   // 10
         // ---- m_p = ReLU(GN_c(t))
         {
             RowVals r = row_load(T, tidv);
@@ -363,28 +385,40 @@ void k_att_pairs_ws(const PairParams p, const int seg) {
                 row_store_lds(T, tidv, r);     // the thread's own 16 floats: no other thread touches them
             }
         }
+        AT_STAMP();   // 11 last row phase done
         if (seg != 0) {
-            __syncthreads();
-            // one thread per (channel, 16-row group): the rows of a target are summed in pair order
+            lds_barrier();
+            // one thread per (channel, 16-row group): the rows of a target are summed in pair order.  The group's 16
+            // target ids (wave-uniform) and the thread's 16 values are fetched up front; the walk itself is
+            // registers only, a store per piece.
             const int c = tidv & (kC - 1), g0 = (tidv >> 7) * 16;
-            int cur = s_hi[g0], first = g0;
+            int t[17];
+            float x[16];
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                const int4 q = *reinterpret_cast<const int4 *>(s_hi + g0 + i);
+                t[i] = q.x; t[i + 1] = q.y; t[i + 2] = q.z; t[i + 3] = q.w;
+            }
+            t[16] = -2;                                    // closes the last piece of the group
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = T[(g0 + i) * kLDA + c];
             float sum = 0.f;
-            if (cur >= 0) {
-#pragma unroll 4
-                for (int i = 0; i < 16; ++i) {
-                    const int t = s_hi[g0 + i];
-                    if (t != cur) {
-                        p.m[(pr0 + first) * kC + c] = sum;
-                        if (t < 0) { cur = -1; break; }
-                        cur = t; first = g0 + i; sum = 0.f;
-                    }
-                    sum += T[(g0 + i) * kLDA + c];
+            int first = 0;
+            float *mrow = p.m + (pr0 + g0) * kC + c;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                sum += x[i];
+                if (t[i + 1] != t[i]) {                    // wave-uniform
+                    if (t[i] >= 0) mrow[first * kC] = sum;
+                    sum = 0.f;
+                    first = i + 1;
                 }
-                if (cur >= 0) p.m[(pr0 + first) * kC + c] = sum;
             }
         }
         hi_c = hi_n; wi_c = wi_n;
-        __syncthreads();      // the next tile rewrites A, T and the index words
+        AT_STAMP();   // 12 pieces written
+        lds_barrier();      // the next tile rewrites A, T and the index words
+        AT_STAMP();   // 13 tile done
     }
 }
 
@@ -446,3 +480,10 @@ extern "C" int lgcn_att_pairs_ws(const float *agt_ctrs, const float *ctx_ctrs, c
     }
     return launch_status();
 }
+
+#ifdef LGCN_STAMPS
+extern "C" void lgcn_debug_att_stamps(void *buf) {
+    unsigned long long *p = reinterpret_cast<unsigned long long *>(buf);
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(lgcn::g_att_stamps), &p, sizeof(p));
+}
+#endif

@@ -23,6 +23,16 @@ using f32x16 = float __attribute__((ext_vector_type(16)));
 // maximum as one instruction (v_maximum3_f32).
 __device__ __forceinline__ float relu_nan(float x) { return __builtin_elementwise_maximum(x, 0.f); }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release/acquire fence over ALL address spaces:
+// hipcc puts s_waitcnt vmcnt(0) in front of the s_barrier, i.e. every global load still in flight (prefetched weight
+// fragments, rows requested for a later phase) and every global store is waited for at each barrier.  Where the threads
+// of a workgroup talk to each other through LDS alone, this barrier lets that traffic stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 inline int launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? LGCN_OK : static_cast<int>(e);

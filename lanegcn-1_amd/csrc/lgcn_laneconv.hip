@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
         for (int j = 0; j < kLcHdr; ++j) h[j] = 0;
     }
     clear();
-    __syncthreads();
+    lds_barrier();
 
     // this row's (first edge, degree, single source) under every unit of the group, fetched up front: two global round
     // trips per workgroup instead of two per unit (the unit loop below is a chain of barriers: latency-bound)
@@ -170,9 +170,9 @@ __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
                 if ((bal >> (16 * j)) & 0xffffull) wm |= 1 << (4 * wave + j);
             if (lane == 0) s_w[wave] = wm;
         }
-        __syncthreads();
+        lds_barrier();
         const int mask = s_w[0] | s_w[1] | s_w[2] | s_w[3];
-        __syncthreads();                              // s_w is rewritten by the next unit
+        lds_barrier();                              // s_w is rewritten by the next unit
         if (tid == 0) maskp[(int64_t)b * kLcUnits + u] = mask;
         if (mask == 0) continue;
         for (int attempt = 0; attempt < 2; ++attempt) {
@@ -187,13 +187,13 @@ __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
                 slot = (int)h;
                 atomicMin(&hrow[slot], tid);
             }
-            __syncthreads();
+            lds_barrier();
             bool winner = deg >= 2;
             if (deg == 1) winner = hval[slot] < 0 && hrow[slot] == tid;
             const unsigned long long bal = __ballot(winner);
             const int wprefix = __popcll(bal & ((1ull << lane) - 1ull));
             if (lane == 0) s_cnt[wave] = __popcll(bal);
-            __syncthreads();
+            lds_barrier();
             int base = 0, total = 0;
 #pragma unroll
             for (int w = 0; w < 4; ++w) { base += w < wave ? s_cnt[w] : 0; total += s_cnt[w]; }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
                     if (deg == 1) hval[slot] = myid;
                 }
                 if (tid == 0) s_ul[n_live] = u;
-                __syncthreads();
+                lds_barrier();
                 int loc = 0xffff;
                 if (deg == 1) loc = hval[slot];
                 else if (deg >= 2) loc = myid;
@@ -216,10 +216,10 @@ __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
             }
             // does not fit: close the item in front of this unit and start a new one here (always fits: total <= M <= cap)
             finalize(cur_u0, n_live, n_src, u - cur_u0);
-            __syncthreads();
+            lds_barrier();
             cur_u0 = u; n_src = 0; n_live = 0;
             clear();
-            __syncthreads();
+            lds_barrier();
         }
     }
     finalize(cur_u0, n_live, n_src, u_end - cur_u0);
@@ -455,7 +455,7 @@ void k_lc_tile(const LcTileParams p) {
             load_loc(uf, lc);
         }
         LC_STAMP();   // own source rows stored
-        __syncthreads();
+        lds_barrier();
         LC_STAMP();   // barrier passed
 
         // ---- units.  Sub-blocks without an edge under a unit read the zero row (their index entries are 0xFFFF),
@@ -573,7 +573,7 @@ void k_lc_tile(const LcTileParams p) {
             LC_STAMP();   // unit k done
         }
         LC_STAMP();       // loop done
-        __syncthreads();  // every wave is done with the source rows (next item's rows / the epilogue tiles go there)
+        lds_barrier();  // every wave is done with the source rows (next item's rows / the epilogue tiles go there)
         u0 += span;
     }
 
@@ -610,7 +610,7 @@ void k_lc_tile(const LcTileParams p) {
             }
         }
         tiles_from_acc(ph);
-        __syncthreads();
+        lds_barrier();
         LC_STAMP();       // both K halves of this row half in LDS
 #pragma unroll
         for (int sweep = 0; sweep < SW; ++sweep) {
@@ -632,7 +632,7 @@ void k_lc_tile(const LcTileParams p) {
             }
         }
         if (finish) {
-            __syncthreads();          // Y planes complete; every read of T0 | T1 is done
+            lds_barrier();          // Y planes complete; every read of T0 | T1 is done
 #pragma unroll
             for (int rb = 0; rb < HRB; ++rb) {
                 acc[ph * HRB + rb][0] = zero4;
@@ -654,7 +654,7 @@ void k_lc_tile(const LcTileParams p) {
                 if (rb + 1 < HRB) rd(yrow + 16 * (rb + 1), 1, a1);
             }
             tiles_from_acc(ph);       // T0 | T1 and the Y planes are disjoint
-            __syncthreads();
+            lds_barrier();
 #pragma unroll
             for (int sweep = 0; sweep < SW; ++sweep) {
                 const int hrow = sweep * 64 + (tid >> 3);
@@ -668,7 +668,7 @@ void k_lc_tile(const LcTileParams p) {
                 }
             }
         }
-        if (ph + 1 < PH) __syncthreads();     // the next row half overwrites the tiles (and the Y planes)
+        if (ph + 1 < PH) lds_barrier();     // the next row half overwrites the tiles (and the Y planes)
     }
     LC_STAMP();           // rows stored
 #ifdef LGCN_STAMPS
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_
     row_gn(r, tid, p.gn1_g, p.gn1_b, p.eps);
     row_relu(r);
     row_split_store<F>(A, TL::PLANE, row, tid, r);
-    __syncthreads();
+    lds_barrier();
     f32x4 acc[2][2];
     acc_zero<2>(acc);
     {
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_
         gemm_pass<2, F>(A, wp2, nullptr, bf, wave, lane, acc);
     }
     acc_store<2>(T, acc, lane, wave);
-    __syncthreads();
+    lds_barrier();
     r = row_load(T, tid);
     row_gn(r, tid, p.gn2_g, p.gn2_b, p.eps);
     row_add(r, resv);

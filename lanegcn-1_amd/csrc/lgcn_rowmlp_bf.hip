@@ -338,7 +338,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
         if (on) act[__popcll(m & ((1ull << lane) - 1ull))] = lane;
         if (lane == 0) act[16] = __popcll(m);
     }
-    __syncthreads();
+    lds_barrier();
     const int nact = __builtin_amdgcn_readfirstlane(act[16]);
     LGCN_STAMP(1);
 
@@ -359,7 +359,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
             if (w0 != nullptr) ring_prime<F>(bfrag, reinterpret_cast<const uint4 *>(w0), wave, lane);
         }
         LGCN_STAMP(2);
-        __syncthreads();
+        lds_barrier();
     }
     LGCN_STAMP(3);
 
@@ -384,7 +384,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
             gather(nxt, rel_at(i + 1));
         }
         LGCN_STAMP(4 + 2 * i);       // own work of pass i done
-        __syncthreads();
+        lds_barrier();
         LGCN_STAMP(5 + 2 * i);       // barrier passed
     }
 
@@ -414,7 +414,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
         acc_store<RB>(T, acc, lane, wave);
     }
     LGCN_STAMP(40);
-    __syncthreads();
+    lds_barrier();
     LGCN_STAMP(41);
 
     // Row-phase ownership: rows 0..31 of the tile belong to waves 4..7 (thread rt -> row rt >> 3), rows 32.. (tiles
@@ -449,7 +449,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     }
     if (!two) return;
     LGCN_STAMP(42);
-    __syncthreads();
+    lds_barrier();
     LGCN_STAMP(43);
     if (wave < 4) {
         acc_zero<RB>(acc);
@@ -457,7 +457,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
         acc_store<RB>(T, acc, lane, wave);   // T and Yp are disjoint; T's readers passed the barrier above
     }
     LGCN_STAMP(44);
-    __syncthreads();
+    lds_barrier();
     LGCN_STAMP(45);
     if (my_has_row) {
         RowVals r = row_load(T + (upper ? 32 : 0) * kLDA, my_rt);
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_mapnet_input_bf(const InputParams p, in
                 lin2_relu_split<F>(A, TL::PLANE, row, tid, v.x, v.y, w1, b1);
             }
         }
-        __syncthreads();
+        lds_barrier();
         acc_zero<RB>(acc);
         {
             BPair<F> bf;
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(256) void k_mapnet_input_bf(const InputParams p, in
             gemm_pass<RB, F>(A, reinterpret_cast<const uint4 *>(wp), nullptr, bf, wave, lane, acc);
         }
         acc_store<RB>(T, acc, lane, wave);
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int c0 = 0; c0 < ROWS; c0 += 32) {
             const int row = c0 + (tid >> 3);
@@ -579,11 +579,11 @@ __global__ __launch_bounds__(256) void k_att_pairs_bf(const PairParams p) {
                 lin2_relu_split<F>(A, TL::PLANE, row, tid, dx, dy, p.wd0, p.bd0);
             }
         }
-        __syncthreads();
+        lds_barrier();
         acc_zero<RB>(acc);
         gemm_pass<RB, F>(A, wd2, wc0, bf, wave, lane, acc);
         acc_store<RB>(T, acc, lane, wave);
-        __syncthreads();   // all waves done reading A; T complete
+        lds_barrier();   // all waves done reading A; T complete
 #pragma unroll
         for (int c0 = 0; c0 < ROWS; c0 += 32) {
             const int row = c0 + (tid >> 3);
@@ -594,11 +594,11 @@ __global__ __launch_bounds__(256) void k_att_pairs_bf(const PairParams p) {
                 row_split_store<F>(A, TL::PLANE, row, tid, r);
             }
         }
-        __syncthreads();
+        lds_barrier();
         acc_zero<RB>(acc);
         gemm_pass<RB, F>(A, wc0, wd2, bf, wave, lane, acc);   // prefetches the next tile's first fragments
         acc_store<RB>(T, acc, lane, wave);   // T's readers (previous row phase) passed the barrier above
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int c0 = 0; c0 < ROWS; c0 += 32) {
             const int row = c0 + (tid >> 3);
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void k_att_pairs_bf(const PairParams p) {
                 if (live) row_store_global(p.m + pr * kC, tid, r);
             }
         }
-        __syncthreads();   // next tile rewrites A (read by the last gemm) and T (read just above)
+        lds_barrier();   // next tile rewrites A (read by the last gemm) and T (read just above)
     }
 }
 
