@@ -148,6 +148,43 @@ int64_t lgcn_index_uv_elems(int64_t n_edges);
 int64_t lgcn_index_cnt_words(int64_t n_nodes, int n_rel);
 int lgcn_index_build(const lgcn_index_t *p_host, void *stream);
 
+/* ------------------------------------------------------------------ */
+/* Graph construction on the device       */
+/* ------------------------------------------------------------------ */
+
+/*
+ * One boolean squaring of a CSR adjacency: the step of data.dilated_nbrs (reference data.py:520-534: the scale-i
+ * relation is A^(2^i), `mat = mat * mat` per scale; u = row, v = column).  Rows may be unsorted and hold duplicates.
+ *   1. lgcn_bool_square_bound  : cand_ptr [n+1] = exclusive scan of the rows' candidate counts; read cand_ptr[n] on
+ *                                the host and allocate cand [cand_ptr[n]].
+ *   2. lgcn_bool_square        : out_rowptr [n+1] = rowptr of A*A (boolean: each entry once, columns ascending); read
+ *                                out_rowptr[n] = nnz and allocate out_col [nnz] (and out_row for a COO).
+ *   3. lgcn_bool_square_compact: out_col (and out_row, may be NULL) filled.
+ * ws: int32 workspace of lgcn_scan_ws_elems(n + 1) elements.  Entries that point outside [0, n) are ignored.
+ */
+int64_t lgcn_scan_ws_elems(int64_t n);
+int lgcn_bool_square_bound(const int32_t *rowptr, const int32_t *col, int64_t n, int32_t *cand_ptr, int32_t *ws,
+                           void *stream);
+int lgcn_bool_square(const int32_t *rowptr, const int32_t *col, int64_t n, const int32_t *cand_ptr, int32_t *cand,
+                     int32_t *out_rowptr, int32_t *ws, void *stream);
+int lgcn_bool_square_compact(const int32_t *cand_ptr, const int32_t *cand, const int32_t *out_rowptr, int64_t n,
+                             int32_t *out_col, int32_t *out_row, void *stream);
+
+/*
+ * Left (or right) node adjacency of one scene: reference preprocess_data.py:287-392 with cross_angle = None, for the
+ * side whose lane pairs are passed (left_pairs or right_pairs; call twice).
+ *   ctrs, feats [n_nodes,2] (segment midpoints / vectors), lane_idcs [n_nodes] int64 (lane of every node),
+ *   side_pairs / pre_pairs / suc_pairs: [k,2] int64 lane pairs; mat: num_lanes^2 bytes of workspace.
+ *   partner [n_nodes]: the node v that node u is linked to (edge u -> v of the reference's `left`/`right` dict), or -1:
+ *   the nearest centre among the nodes of the lanes (S pre + S suc + S)[lane(u)] allows, if it is closer than
+ *   cross_dist and the two headings differ by less than pi / 4.  Distances are formed exactly as ATen does (fp32,
+ *   no FMA), ties go to the smaller node index; the heading test uses atan2f (its last bit may differ from ATen's).
+ */
+int lgcn_cross_edges(const float *ctrs, const float *feats, const int64_t *lane_idcs, int64_t n_nodes, int num_lanes,
+                     const int64_t *side_pairs, int64_t n_side, const int64_t *pre_pairs, int64_t n_pre,
+                     const int64_t *suc_pairs, int64_t n_suc, float cross_dist, uint8_t *mat, int32_t *partner,
+                     void *stream);
+
 /* int32 -> int64 widening of the first *n (device count, clamped to cap)
  * entries; the tail is left untouched.  Used to hand hi/wi back as the
  * reference's LongTensors. */

@@ -114,6 +114,11 @@ SIGNATURES = {
     "lgcn_check_finite": (C.c_int, [_P, _L, _P, _L, _P, _I, _P]),
     "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
     "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
+    "lgcn_scan_ws_elems": (C.c_int64, [_L]),
+    "lgcn_bool_square_bound": (C.c_int, [_P, _P, _L, _P, _P, _P]),
+    "lgcn_bool_square": (C.c_int, [_P, _P, _L, _P, _P, _P, _P, _P]),
+    "lgcn_bool_square_compact": (C.c_int, [_P, _P, _P, _L, _P, _P, _P]),
+    "lgcn_cross_edges": (C.c_int, [_P, _P, _P, _L, _I, _P, _L, _P, _L, _P, _L, _F, _P, _P, _P]),
     "lgcn_index_uv_elems": (C.c_int64, [_L]),
     "lgcn_index_cnt_words": (C.c_int64, [_L, _I]),
     "lgcn_index_build": (C.c_int, [_P, _P]),

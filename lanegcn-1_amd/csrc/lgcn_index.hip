@@ -471,6 +471,129 @@ __global__ __launch_bounds__(256) void k_index_sort(const IndexParams p) {
     }
 }
 
+// -------------------------------------------- graph construction (row f3) -----
+// dilated_nbrs (reference data.py:520-534): the scale-i relation is the boolean power A^(2^i) of the scale-0
+// adjacency, formed by repeated squaring (mat = mat * mat).  One squaring of a CSR matrix with sorted or unsorted
+// rows (duplicates allowed: they only repeat candidates):
+//   bound  : cand_ptr[u] = exclusive scan of sum_{v in A[u]} |A[v]|
+//   expand : row u's candidates {w : w in A[v], v in A[u]} -> sorted, duplicates removed in place, count kept
+//   compact: rows packed to the scanned counts (+ the COO row index of every entry)
+// One thread per row: lane graphs branch rarely, a row of A^32 has a handful of entries.
+__global__ __launch_bounds__(256) void k_sq_bound(const int32_t *rowptr, const int32_t *col, int64_t n, int32_t *ub) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u > n) return;
+    int s = 0;
+    if (u < n)
+        for (int e = rowptr[u]; e < rowptr[u + 1]; ++e) {
+            const int v = col[e];
+            if (v >= 0 && v < n) s += rowptr[v + 1] - rowptr[v];
+        }
+    ub[u] = s;        // ub[n] = 0: the scan leaves the total there
+}
+
+__global__ __launch_bounds__(256) void k_sq_expand(const int32_t *rowptr, const int32_t *col, int64_t n,
+                                                   const int32_t *cand_ptr, int32_t *cand, int32_t *cnt) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u > n) return;
+    if (u == n) { cnt[n] = 0; return; }
+    int32_t *c = cand + cand_ptr[u];
+    int k = 0;
+    for (int e = rowptr[u]; e < rowptr[u + 1]; ++e) {
+        const int v = col[e];
+        if (v < 0 || v >= n) continue;
+        for (int f = rowptr[v]; f < rowptr[v + 1]; ++f) {      // insertion into the sorted, duplicate-free prefix
+            const int w = col[f];
+            int q = k - 1;
+            while (q >= 0 && c[q] > w) --q;
+            if (q >= 0 && c[q] == w) continue;
+            for (int r = k; r > q + 1; --r) c[r] = c[r - 1];
+            c[q + 1] = w;
+            ++k;
+        }
+    }
+    cnt[u] = k;
+}
+
+__global__ __launch_bounds__(256) void k_sq_compact(const int32_t *cand_ptr, const int32_t *cand, const int32_t *out_rowptr,
+                                                    int64_t n, int32_t *out_col, int32_t *out_row) {
+    const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n) return;
+    const int b = out_rowptr[u], k = out_rowptr[u + 1] - b;
+    const int32_t *c = cand + cand_ptr[u];
+    for (int i = 0; i < k; ++i) {
+        out_col[b + i] = c[i];
+        if (out_row) out_row[b + i] = (int32_t)u;
+    }
+}
+
+// Left / right node adjacency (reference preprocess_data.py:287-392, cross_angle = None).
+// Lane-level mask (:318-327 / :356-360): mat = (S pre + S suc + S) > 0.5 with S, pre, suc the 0/1 matrices of the side
+// pairs and the predecessor / successor lane pairs: mat[a][b] = S[a][b] or exists c: S[a][c] and (pre[c][b] or suc[c][b]).
+__global__ __launch_bounds__(256) void k_lane_mask(const int64_t *side, int64_t n_side, const int64_t *pre, int64_t n_pre,
+                                                   const int64_t *suc, int64_t n_suc, int num_lanes, uint8_t *mat) {
+    const int64_t per = n_pre + n_suc + 1;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_side * per) return;
+    const int64_t i = t / per, j = t % per;
+    const int64_t a = side[2 * i], c = side[2 * i + 1];
+    if (a < 0 || a >= num_lanes || c < 0 || c >= num_lanes) return;
+    int64_t b = c;
+    if (j > 0) {
+        const int64_t *pp = j - 1 < n_pre ? pre + 2 * (j - 1) : suc + 2 * (j - 1 - n_pre);
+        if (pp[0] != c) return;
+        b = pp[1];
+        if (b < 0 || b >= num_lanes) return;
+    }
+    mat[a * num_lanes + b] = 1;
+}
+
+// One wave per node h (:329-347): over the nodes w whose lane is allowed for h's lane, the nearest centre (fp32
+// sub / mul / add / sqrt as ATen evaluates sqrt(((a - b) ** 2).sum(2)); the FIRST w among equals, as a CPU min(1)
+// returns); kept when the distance is < cross_dist and the two segments' headings differ by < pi / 4.
+__global__ __launch_bounds__(256) void k_cross_edges(const float2 *ctrs, const float2 *feats, const int64_t *lane_idcs,
+                                                     int n, const uint8_t *mat, int num_lanes, float cross_dist,
+                                                     int32_t *partner) {
+    const int lane = threadIdx.x & 63;
+    const int h = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (h >= n) return;
+    const float2 a = ctrs[h];
+    const int64_t la = lane_idcs[h];
+    const bool la_ok = la >= 0 && la < num_lanes;
+    float best = 3.0e38f;
+    int bw = 0x7fffffff;
+    for (int w0 = 0; w0 < n; w0 += 64) {
+        const int w = w0 + lane;
+        if (w < n) {
+            const int64_t lb = lane_idcs[w];
+            const bool ok = la_ok && lb >= 0 && lb < num_lanes && mat[la * num_lanes + lb] != 0;
+            float d = 1e6f;                                     // :332 masked entries
+            if (ok) {
+                const float2 c = ctrs[w];
+                const float dx = __fsub_rn(a.x, c.x), dy = __fsub_rn(a.y, c.y);
+                d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
+            }
+            if (d < best) { best = d; bw = w; }                 // ascending w per lane: the first of equals stays
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int ow = __shfl_xor(bw, off, 64);
+        if (ob < best || (ob == best && ow < bw)) { best = ob; bw = ow; }
+    }
+    if (lane == 0) {
+        int out = -1;
+        if (best < cross_dist && bw < n) {
+            const float2 f1 = feats[h], f2 = feats[bw];
+            const float t1 = atan2f(f1.y, f1.x), t2 = atan2f(f2.y, f2.x);
+            float dt = fabsf(__fsub_rn(t1, t2));
+            if (dt > 3.14159274101257324f) dt = fabsf(__fsub_rn(dt, 6.28318548202514648f));      // float32(pi), float32(2 pi)
+            if (dt < 0.785398185253143311f) out = bw;                                            // float32(pi / 4)
+        }
+        partner[h] = out;
+    }
+}
+
 // rowptr and cursor of the CSR plan zeroed in one launch (two memset nodes cost a launch boundary each)
 __global__ __launch_bounds__(256) void k_zero2(int32_t *a, int32_t *b, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -692,6 +815,65 @@ int lgcn_index_build(const lgcn_index_t *ph, void *stream) {
     hipLaunchKernelGGL(k_index_scan, dim3((unsigned)(p.scan_blocks + q.n_jobs)), dim3(1024), 0, st, p);
     if (g13 > 0) hipLaunchKernelGGL((k_index_edges<1>), dim3(g13), dim3(256), 0, st, p);
     if (total > 0) hipLaunchKernelGGL(k_index_sort, dim3((unsigned)((nk1 + 255) / 256)), dim3(256), 0, st, p);
+    return launch_status();
+}
+
+int lgcn_bool_square_bound(const int32_t *rowptr, const int32_t *col, int64_t n, int32_t *cand_ptr, int32_t *ws,
+                            void *stream) {
+    if (n < 0) return LGCN_EINVAL;
+    if (n > 0x7ffffff0) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(rowptr); LGCN_CHECK_PTR(cand_ptr); LGCN_CHECK_PTR(ws);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sq_bound, dim3(grid_for(n + 1, 256, 1 << 22)), dim3(256), 0, st, rowptr, col, n, cand_ptr);
+    return exclusive_scan(cand_ptr, cand_ptr, n + 1, ws, st);
+}
+
+int lgcn_bool_square(const int32_t *rowptr, const int32_t *col, int64_t n, const int32_t *cand_ptr, int32_t *cand,
+                     int32_t *out_rowptr, int32_t *ws, void *stream) {
+    if (n < 0) return LGCN_EINVAL;
+    if (n > 0x7ffffff0) return LGCN_ESHAPE;
+    LGCN_CHECK_PTR(rowptr); LGCN_CHECK_PTR(cand_ptr); LGCN_CHECK_PTR(out_rowptr); LGCN_CHECK_PTR(ws);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_sq_expand, dim3(grid_for(n + 1, 256, 1 << 22)), dim3(256), 0, st, rowptr, col, n, cand_ptr, cand,
+                       out_rowptr);
+    return exclusive_scan(out_rowptr, out_rowptr, n + 1, ws, st);
+}
+
+int lgcn_bool_square_compact(const int32_t *cand_ptr, const int32_t *cand, const int32_t *out_rowptr, int64_t n,
+                             int32_t *out_col, int32_t *out_row, void *stream) {
+    if (n < 0) return LGCN_EINVAL;
+    if (n == 0) return LGCN_OK;
+    LGCN_CHECK_PTR(cand_ptr); LGCN_CHECK_PTR(out_rowptr);
+    hipLaunchKernelGGL(k_sq_compact, dim3(grid_for(n, 256, 1 << 22)), dim3(256), 0, (hipStream_t)stream, cand_ptr, cand,
+                       out_rowptr, n, out_col, out_row);
+    return launch_status();
+}
+
+int64_t lgcn_scan_ws_elems(int64_t n) { return n < 0 ? (int64_t)LGCN_EINVAL : scan_ws_elems(n); }
+
+int lgcn_cross_edges(const float *ctrs, const float *feats, const int64_t *lane_idcs, int64_t n_nodes, int num_lanes,
+                     const int64_t *side_pairs, int64_t n_side, const int64_t *pre_pairs, int64_t n_pre,
+                     const int64_t *suc_pairs, int64_t n_suc, float cross_dist, uint8_t *mat, int32_t *partner,
+                     void *stream) {
+    if (n_nodes < 0 || num_lanes < 0 || n_side < 0 || n_pre < 0 || n_suc < 0) return LGCN_EINVAL;
+    if (n_nodes > 0x7ffffff0 || (int64_t)num_lanes * num_lanes > 0x7ffffff0) return LGCN_ESHAPE;
+    if (n_nodes == 0) return LGCN_OK;
+    LGCN_CHECK_PTR(ctrs); LGCN_CHECK_PTR(feats); LGCN_CHECK_PTR(lane_idcs); LGCN_CHECK_PTR(partner);
+    if (num_lanes > 0) LGCN_CHECK_PTR(mat);
+    if (n_side > 0) LGCN_CHECK_PTR(side_pairs);
+    if (n_pre > 0) LGCN_CHECK_PTR(pre_pairs);
+    if (n_suc > 0) LGCN_CHECK_PTR(suc_pairs);
+    hipStream_t st = (hipStream_t)stream;
+    if (num_lanes > 0) {
+        hipError_t e = hipMemsetAsync(mat, 0, (size_t)num_lanes * num_lanes, st);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int64_t work = n_side * (n_pre + n_suc + 1);
+    if (work > 0)
+        hipLaunchKernelGGL(k_lane_mask, dim3(grid_for(work, 256, 1 << 22)), dim3(256), 0, st, side_pairs, n_side, pre_pairs,
+                           n_pre, suc_pairs, n_suc, num_lanes, mat);
+    hipLaunchKernelGGL(k_cross_edges, dim3((unsigned)((n_nodes + 3) / 4)), dim3(256), 0, st, (const float2 *)ctrs,
+                       (const float2 *)feats, lane_idcs, (int)n_nodes, mat, num_lanes, cross_dist, partner);
     return launch_status();
 }
 

@@ -359,6 +359,59 @@ def index_build(idx_local: torch.Tensor, seg_off: torch.Tensor, seg_base: torch.
     return plan, pairs
 
 
+# ------------------------------------------------------------------ graph construction (row f3)
+def dilated_nbrs(u: torch.Tensor, v: torch.Tensor, num_nodes: int, num_scales: int):
+    """Scales 1 .. num_scales - 1 of a relation on the device (reference data.dilated_nbrs, data.py:520-534): the
+    boolean powers A^(2^i) of the scale-0 adjacency by repeated squaring.  u, v: int64 device tensors (edge u <- v,
+    i.e. row u, column v).  Returns a list of {"u", "v"} int64 device tensors, rows ascending, columns ascending
+    within a row, every edge once.  Two host reads per scale (the sizes of the candidate and result arrays)."""
+    lib = L.load()
+    plan = csr_build([u], [v], num_nodes)              # one relation: key(n, 0) = n, a plain CSR by row
+    n = plan.rowptr.numel() - 1                        # rows padded to a multiple of 16 (the padding rows are empty)
+    dev = plan.rowptr.device
+    rowptr, col = plan.rowptr, plan.col
+    i32 = dict(dtype=torch.int32, device=dev)
+    ws = torch.empty(max(lib.lgcn_scan_ws_elems(n + 1), 1), **i32)
+    out = []
+    for _ in range(1, num_scales):
+        cand_ptr = torch.empty(n + 1, **i32)
+        L.check(lib.lgcn_bool_square_bound(_ptr(rowptr), _ptr(col), n, _ptr(cand_ptr), _ptr(ws), _stream()),
+                "lgcn_bool_square_bound")
+        cand = torch.empty(max(int(cand_ptr[n].item()), 1), **i32)
+        out_rowptr = torch.empty(n + 1, **i32)
+        L.check(lib.lgcn_bool_square(_ptr(rowptr), _ptr(col), n, _ptr(cand_ptr), _ptr(cand), _ptr(out_rowptr), _ptr(ws),
+                                     _stream()), "lgcn_bool_square")
+        nnz = int(out_rowptr[n].item())
+        out_col, out_row = torch.empty(max(nnz, 1), **i32), torch.empty(max(nnz, 1), **i32)
+        L.check(lib.lgcn_bool_square_compact(_ptr(cand_ptr), _ptr(cand), _ptr(out_rowptr), n, _ptr(out_col), _ptr(out_row),
+                                             _stream()), "lgcn_bool_square_compact")
+        out.append({"u": out_row[:nnz].long(), "v": out_col[:nnz].long()})
+        rowptr, col = out_rowptr, out_col
+    return out
+
+
+def cross_edges(ctrs: torch.Tensor, feats: torch.Tensor, lane_idcs: torch.Tensor, num_lanes: int,
+                side_pairs: torch.Tensor, pre_pairs: torch.Tensor, suc_pairs: torch.Tensor, cross_dist: float):
+    """Left (or right) node adjacency of one scene (lgcn_cross_edges; reference preprocess_data.py:287-392 without
+    cross_angle): returns (u, v) int64 device tensors, u ascending."""
+    lib = L.load()
+    ctrs = _dev(ctrs, torch.float32, "ctrs")
+    feats = _dev(feats, torch.float32, "feats")
+    lane_idcs = _dev(lane_idcs, torch.int64, "lane_idcs")
+    n = ctrs.shape[0]
+    pairs = [_dev(t.reshape(-1, 2), torch.int64, "pairs") for t in (side_pairs, pre_pairs, suc_pairs)]
+    dev = ctrs.device
+    partner = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    mat = torch.empty(max(num_lanes * num_lanes, 1), dtype=torch.uint8, device=dev)
+    L.check(lib.lgcn_cross_edges(_ptr(ctrs), _ptr(feats), _ptr(lane_idcs), n, num_lanes,
+                                 _ptr(pairs[0]), pairs[0].shape[0], _ptr(pairs[1]), pairs[1].shape[0],
+                                 _ptr(pairs[2]), pairs[2].shape[0], float(cross_dist), _ptr(mat), _ptr(partner),
+                                 _stream()), "lgcn_cross_edges")
+    partner = partner[:n]
+    u = torch.nonzero(partner >= 0).reshape(-1)
+    return u, partner[u].long()
+
+
 # ------------------------------------------------------------------ weight packing
 def _cached(weight: torch.Tensor, key, make):
     """Per-tensor-object cache, valid while (data_ptr, _version) are unchanged.  Living on the

@@ -357,5 +357,73 @@ def out_t(a):
     return torch.from_numpy(a.copy())
 
 
+def graphgen_scene(rng, n_lanes, seg_per_lane, side_p=1.0, far=False):
+    """Raw lane topology of one synthetic scene (what ArgoDataset.get_lane_graph hands to `preprocess`, reference
+    data.py:220-361): `n_lanes` parallel lanes of a road bent along an arc, each cut into consecutive LANE SEGMENTS
+    (the reference's "lanes") of `seg_per_lane` nodes; segment k of lane j follows segment k - 1 (pre / suc pairs) and
+    has lane j - 1 / j + 1's segment k as left / right neighbour (kept with probability side_p)."""
+    n_seg = int(rng.integers(2, 5))
+    ctrs, feats, lane_idcs = [], [], []
+    pre_pairs, suc_pairs, left_pairs, right_pairs = [], [], [], []
+    radius = float(rng.uniform(40.0, 200.0))
+    lane_id = lambda j, k: j * n_seg + k
+    for j in range(n_lanes):
+        r = radius + 3.5 * j * (40.0 if far else 1.0)
+        m = n_seg * seg_per_lane + 1
+        ang = np.linspace(0.0, 2.0 * m / radius, m + 1) + rng.normal(0, 1e-3, m + 1)
+        pts = np.stack([r * np.cos(ang), r * np.sin(ang)], 1)
+        c, f = (pts[:-1] + pts[1:]) / 2, pts[1:] - pts[:-1]
+        for k in range(n_seg):
+            sl = slice(k * seg_per_lane, (k + 1) * seg_per_lane)
+            ctrs.append(c[sl]); feats.append(f[sl])
+            lane_idcs.append(np.full(seg_per_lane, lane_id(j, k)))
+            if k > 0:
+                pre_pairs.append([lane_id(j, k), lane_id(j, k - 1)])
+                suc_pairs.append([lane_id(j, k - 1), lane_id(j, k)])
+            if j > 0 and rng.random() < side_p:
+                right_pairs.append([lane_id(j, k), lane_id(j - 1, k)])
+            if j + 1 < n_lanes and rng.random() < side_p:
+                left_pairs.append([lane_id(j, k), lane_id(j + 1, k)])
+    arr = lambda x: np.asarray(x, np.int64).reshape(-1, 2)
+    return dict(ctrs=np.concatenate(ctrs).astype(np.float32), feats=np.concatenate(feats).astype(np.float32),
+                lane_idcs=np.concatenate(lane_idcs).astype(np.int64), pre_pairs=arr(pre_pairs), suc_pairs=arr(suc_pairs),
+                left_pairs=arr(left_pairs), right_pairs=arr(right_pairs))
+
+
+def graphgen_fixture():
+    """Row f3: the reference's own `preprocess` (preprocess_data.py:287-392, cross_angle = None, cross_dist = 6 as
+    lanegcn.py's config) on six synthetic raw lane topologies; inputs and the left / right edges it returns."""
+    import torch
+    import_reference()
+    import preprocess_data as refpp
+    from oracle import graphgen_oracle as GO
+    torch.set_num_threads(1)
+    rng = np.random.default_rng(41)
+    specs = [dict(n_lanes=3, seg_per_lane=9), dict(n_lanes=5, seg_per_lane=6, side_p=0.6), dict(n_lanes=2, seg_per_lane=12),
+             dict(n_lanes=4, seg_per_lane=7, far=True), dict(n_lanes=6, seg_per_lane=5, side_p=0.8), dict(n_lanes=1, seg_per_lane=8)]
+    out = {"cross_dist": np.float32(6.0), "n_scenes": np.int64(len(specs))}
+    for i, sp in enumerate(specs):
+        g = graphgen_scene(rng, **sp)
+        if i == 2:
+            g["left_pairs"] = np.zeros((0, 2), np.int64)               # the empty-side branch (:348-350)
+        tg = {k: torch.from_numpy(v) for k, v in g.items()}
+        tg["idx"] = i
+        res = refpp.preprocess(tg, 6.0)
+        mine = GO.preprocess(g, 6.0)
+        for side in ("left", "right"):
+            u, v = res[side]["u"], res[side]["v"]
+            assert u.dtype == np.int16 and np.array_equal(u, mine[side]["u"]) and np.array_equal(v, mine[side]["v"]), (i, side)
+            out["g%d/%s/u" % (i, side)], out["g%d/%s/v" % (i, side)] = u, v
+        for k, v in g.items():
+            out["g%d/%s" % (i, k)] = v
+        print("scene %d: %d nodes, %d lanes, left %d right %d edges" % (
+            i, len(g["lane_idcs"]), int(g["lane_idcs"][-1]) + 1, len(res["left"]["u"]), len(res["right"]["u"])))
+    np.savez_compressed(os.path.join(HERE, "graphgen_b6.npz"), **out)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "graphgen":
+        graphgen_fixture()
+    else:
+        main()
+        graphgen_fixture()

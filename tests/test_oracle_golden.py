@@ -126,3 +126,32 @@ def test_dilated_nbrs_vs_the_reference_itself(golden):
                 assert np.array_equal(suv[np.lexsort((suv[:, 1], suv[:, 0]))], want)
                 seen += 1
     assert seen == 40
+
+
+def load_graphgen():
+    import os
+    from conftest import GOLDEN_DIR
+    with np.load(os.path.join(GOLDEN_DIR, "graphgen_b6.npz")) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_preprocess_oracle_vs_the_reference_itself():
+    """Row f3: the numpy restatement of `preprocess` (reference preprocess_data.py:287-392) against the left / right
+    edges the reference's own function returned for six raw lane topologies (tests/golden/make_golden.py graphgen);
+    and no candidate of the fixture sits within 1e-4 rad of the pi / 4 heading threshold, so that the last bit of an
+    atan2 implementation cannot decide an edge."""
+    from oracle import graphgen_oracle as GO
+    z = load_graphgen()
+    n_edges = 0
+    for i in range(int(z["n_scenes"])):
+        g = {k: z["g%d/%s" % (i, k)] for k in ("ctrs", "feats", "lane_idcs", "pre_pairs", "suc_pairs", "left_pairs", "right_pairs")}
+        got = GO.preprocess(g, float(z["cross_dist"]))
+        for side in ("left", "right"):
+            assert np.array_equal(got[side]["u"], z["g%d/%s/u" % (i, side)]), (i, side)
+            assert np.array_equal(got[side]["v"], z["g%d/%s/v" % (i, side)]), (i, side)
+            assert got[side]["u"].dtype == np.int16
+            n_edges += len(got[side]["u"])
+        n = len(g["lane_idcs"])
+        hi, wi = np.repeat(np.arange(n), n), np.tile(np.arange(n), n)
+        assert GO.heading_margin(g["feats"], hi, wi).min() > 1e-4
+    assert n_edges == 351
