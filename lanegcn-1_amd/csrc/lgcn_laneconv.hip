@@ -21,6 +21,10 @@
 #include "lgcn_tile.hpp"
 #include "lgcn_mma_bf.hpp"
 
+#ifndef LGCN_V3_DBUF
+#define LGCN_V3_DBUF 0
+#endif
+
 namespace lgcn {
 
 constexpr int kLcUnits = LGCN_LC_UNITS;     // ctr + up to 14 lane relations
@@ -43,6 +47,12 @@ template <> struct LcCfg<2, 1> { static constexpr int RBN = 12, CAP = 304, HRB =
 // n_groups = 1): half the rows of the shared shape, so that ~2 x as many CUs work, every source row of the 15 units in
 // one item, a second weight register set so that the next unit's 64 KB slice streams in under this unit's MFMAs
 // (with <= 48 rows the L2 -> CU weight stream, not the matrix pipe, is what a unit costs).
+// V = 3 "short, shared": the short row block within the shared shape's budget (<= 128 VGPRs, <= 79 KB of LDS: CAP is the
+// most source rows a 48-row block of the S2 lane graphs names), so that TWO workgroups -- of one launch, or of two
+// forwards in flight -- share a CU and run their prologues / epilogues under each other's MFMA phases.
+template <> struct LcCfg<0, 3> { static constexpr int RBN = 2, CAP = 100, HRB = 2; };
+template <> struct LcCfg<1, 3> { static constexpr int RBN = 3, CAP = 156, HRB = 3; };
+template <> struct LcCfg<2, 3> { static constexpr int RBN = 3, CAP = 156, HRB = 3; };
 template <> struct LcCfg<0, 2> { static constexpr int RBN = 2, CAP = 112, HRB = 2; };
 template <> struct LcCfg<1, 2> { static constexpr int RBN = 3, CAP = 176, HRB = 3; };
 template <> struct LcCfg<2, 2> { static constexpr int RBN = 3, CAP = 176, HRB = 3; };
@@ -273,16 +283,17 @@ struct LcGeom {
     static constexpr int YR0 = 0, TOFF = HR * ROWB;
     static constexpr int EP_BYTES = TOFF + T2_BYTES, SRC_BYTES = (CAP + 1) * ROWB;
     static constexpr int SMEM = SRC_BYTES > EP_BYTES ? SRC_BYTES : EP_BYTES;
-    static_assert(RBN % HRB == 0 && SMEM <= (V == 0 ? 78 : V == 1 ? 160 : 96) * 1024 - 256, "row block does not fit the LDS");
+    static_assert(RBN % HRB == 0 && SMEM <= (V == 0 ? 78 * 1024 - 256 : V == 1 ? 160 * 1024 - 256 : V == 2 ? 96 * 1024 : 80 * 1024 - 1024),
+                  "row block does not fit the LDS");
 };
 
 template <int F, int V, bool FIN>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(V == 0 ? 4 : 2)))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(V == 0 || V == 3 ? 4 : 2)))
 void k_lc_tile(const LcTileParams p) {
     using G = LcGeom<F, V>;
     constexpr int RBN = G::RBN, CAP = G::CAP, NP = G::NP, ROWB = G::ROWB, M = G::M, HRB = G::HRB, HR = G::HR, PH = G::PH;
     constexpr int NIT = (CAP + 15) / 16;
-    constexpr bool DBUF = V >= 1;                      // tall / short: a second weight-slice register set (256 VGPRs to spend)
+    constexpr bool DBUF = V == 1 || V == 2 || (V == 3 && LGCN_V3_DBUF);     // a second weight-slice register set
     constexpr int NLC = RBN > 8 ? 2 : 1;               // uint4 words of the per-row index
     constexpr bool PIPE = V == 2;                      // short: A fragments requested NB - 1 sub-blocks ahead
     constexpr int NB = RBN % 2 == 0 ? 2 : 3, PD = NB - 1;
@@ -754,8 +765,8 @@ __global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_
 static int fmt_of(int mma) { return mma == LGCN_MMA_BF16X3 ? 0 : mma == LGCN_MMA_F16X2 ? 1 : 2; }
 
 static bool lc_cfg(int mma, int variant, int *M, int *cap) {
-    if (variant < 0 || variant > 2) return false;
-#define LGCN_CFG(F_) do { if (variant == 2) { *M = 16 * LcCfg<F_, 2>::RBN; *cap = LcCfg<F_, 2>::CAP; } else if (variant) { *M = 16 * LcCfg<F_, 1>::RBN; *cap = LcCfg<F_, 1>::CAP; } else { *M = 16 * LcCfg<F_, 0>::RBN; *cap = LcCfg<F_, 0>::CAP; } } while (0)
+    if (variant < 0 || variant > 3) return false;
+#define LGCN_CFG(F_) do { if (variant == 3) { *M = 16 * LcCfg<F_, 3>::RBN; *cap = LcCfg<F_, 3>::CAP; } else if (variant == 2) { *M = 16 * LcCfg<F_, 2>::RBN; *cap = LcCfg<F_, 2>::CAP; } else if (variant) { *M = 16 * LcCfg<F_, 1>::RBN; *cap = LcCfg<F_, 1>::CAP; } else { *M = 16 * LcCfg<F_, 0>::RBN; *cap = LcCfg<F_, 0>::CAP; } } while (0)
     switch (fmt_of(mma)) {
         case 0: LGCN_CFG(0); break;
         case 1: LGCN_CFG(1); break;
@@ -838,10 +849,12 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
     if (!lc_mma_ok(q.mma)) return LGCN_ESHAPE;
     const int M = q.rows_per_block;
     int variant = -1, capv = 0;
-    for (int v = 0; v < 3; ++v) {
+    // the short shapes share their row-block height: the capacity tells them apart (a plan built for the shared one
+    // fits both; the larger budget is used only when the plan needs it)
+    for (int v = 0; v < 4; ++v) {
         int Mv, cv;
         lc_cfg(q.mma, v, &Mv, &cv);
-        if (Mv == M) { variant = v; capv = cv; }
+        if (Mv == M && q.cap <= cv && (variant < 0 || cv < capv)) { variant = v; capv = cv; }
     }
     if (q.n_rows < 0 || variant < 0 || q.cap < M || q.cap > capv || q.n_rows > 0x7fffffff) return LGCN_EINVAL;
     if (!lc_groups_ok(q.n_units, q.n_groups, q.gstart)) return LGCN_EINVAL;
@@ -876,7 +889,8 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
     const int n_tiles = (int)((q.n_rows + 31) / 32);
 #define LGCN_LCV(F_, FIN_)                                                                                   \
     do {                                                                                                     \
-        if (variant == 2) hipLaunchKernelGGL((k_lc_tile<F_, 2, FIN_>), dim3(grid1), dim3(512), 0, st, t);     \
+        if (variant == 3) hipLaunchKernelGGL((k_lc_tile<F_, 3, FIN_>), dim3(grid1), dim3(512), 0, st, t);     \
+        else if (variant == 2) hipLaunchKernelGGL((k_lc_tile<F_, 2, FIN_>), dim3(grid1), dim3(512), 0, st, t); \
         else if (variant == 1) hipLaunchKernelGGL((k_lc_tile<F_, 1, FIN_>), dim3(grid1), dim3(512), 0, st, t); \
         else hipLaunchKernelGGL((k_lc_tile<F_, 0, FIN_>), dim3(grid1), dim3(512), 0, st, t);                  \
     } while (0)
