@@ -143,6 +143,8 @@ typedef struct {
     void *cnt;
     int32_t *uv;
     const lgcn_pairs_job_t *jobs; int32_t n_jobs, pad_;
+    int32_t *clear_word;     /* optional (may be NULL): a 32-bit word the first launch sets to 0 -- the forward's
+                                range-guard flag (lgcn_check_finite) rides along instead of costing a fill launch */
 } lgcn_index_t;
 int64_t lgcn_index_uv_elems(int64_t n_edges);
 int64_t lgcn_index_cnt_words(int64_t n_nodes, int n_rel);

@@ -38,6 +38,7 @@ class Index(C.Structure):         # lgcn_index_t
         ("n_nodes", C.c_int64),
         ("rowptr", C.c_void_p), ("col", C.c_void_p), ("cnt", C.c_void_p), ("uv", C.c_void_p),
         ("jobs", C.c_void_p), ("n_jobs", C.c_int32), ("pad_", C.c_int32),
+        ("clear_word", C.c_void_p),
     ]
 
 

@@ -364,6 +364,7 @@ struct IndexParams {
     int32_t *rowptr, *col;
     int edge_blocks, scan_blocks, n_jobs;
     int job_blocks[5];                        // prefix of the pair jobs' row-block counts
+    int32_t *clear_word;                      // optional word zeroed by the count pass
     PairsJobs jobs;
 };
 
@@ -380,6 +381,7 @@ template <int PASS>     // 0: count, 1: fill
 __global__ __launch_bounds__(256) void k_index_edges(const IndexParams p) {
     __shared__ int s_tile[kIdxMaxTiles];
     const int bid = blockIdx.x;
+    if (PASS == 0 && bid == 0 && threadIdx.x == 0 && p.clear_word) *p.clear_word = 0;
     if (bid >= p.edge_blocks) {               // pair-search workgroups
         const int b = bid - p.edge_blocks;
         int jn = 0;
@@ -786,6 +788,7 @@ int lgcn_index_build(const lgcn_index_t *ph, void *stream) {
     p.n_nodes = q.n_nodes; p.n_keys1 = nk1;
     p.cnt = reinterpret_cast<unsigned long long *>(q.cnt); p.uv = q.uv; p.rowptr = q.rowptr; p.col = q.col;
     p.n_jobs = q.n_jobs;
+    p.clear_word = q.clear_word;
     p.job_blocks[0] = 0;
     for (int k = 0; k < 4; ++k) {
         if (k < q.n_jobs) {
@@ -812,6 +815,7 @@ int lgcn_index_build(const lgcn_index_t *ph, void *stream) {
     hipStream_t st = (hipStream_t)stream;
     const unsigned g13 = (unsigned)(p.edge_blocks + p.job_blocks[4]);
     if (g13 > 0) hipLaunchKernelGGL((k_index_edges<0>), dim3(g13), dim3(256), 0, st, p);
+    else if (q.clear_word) { hipError_t e = hipMemsetAsync(q.clear_word, 0, 4, st); if (e != hipSuccess) return (int)e; }
     hipLaunchKernelGGL(k_index_scan, dim3((unsigned)(p.scan_blocks + q.n_jobs)), dim3(1024), 0, st, p);
     if (g13 > 0) hipLaunchKernelGGL((k_index_edges<1>), dim3(g13), dim3(256), 0, st, p);
     if (total > 0) hipLaunchKernelGGL(k_index_sort, dim3((unsigned)((nk1 + 255) / 256)), dim3(256), 0, st, p);

@@ -159,6 +159,11 @@ class SyntheticArgoDataset(torch.utils.data.Dataset):
     the dataset, both absent): same constructor signature and item schema, scenes from synth_scene."""
 
     def __init__(self, split=None, config=None, train=True, length=64, roads=(6, 6, 6), n_actors=50, seed=0):
+        if split:      # a real split path was given: say loudly that it is NOT being read
+            import warnings
+            warnings.warn("SyntheticArgoDataset ignores the split path %r: scenes are random synthetic lane graphs "
+                          "(put the real ArgoDataset class in config['dataset_cls'] to train / evaluate on data)" % (split,),
+                          RuntimeWarning, stacklevel=2)
         self.config, self.train = config, train
         self.length, self.roads, self.n_actors, self.seed = int(length), list(roads), n_actors, seed
 

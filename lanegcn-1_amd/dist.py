@@ -101,3 +101,20 @@ def allreduce_mean_grads(params: Iterable[torch.nn.Parameter]):
         else:
             p.grad.copy_(g)
         off += n
+
+
+def gather_metrics(metrics: dict) -> dict:
+    """The reference's `sync` (train.py:245-259, an MPI allgather + merge): scalars are summed over ranks, lists of
+    per-batch arrays are concatenated in rank order.  Single process: returned as is."""
+    if not (torch.distributed.is_available() and torch.distributed.is_initialized()) or torch.distributed.get_world_size() == 1:
+        return metrics
+    parts = [None] * torch.distributed.get_world_size()
+    torch.distributed.all_gather_object(parts, metrics)
+    out = {}
+    for part in parts:
+        for k, v in (part or {}).items():
+            if isinstance(v, list):
+                out.setdefault(k, []).extend(v)
+            else:
+                out[k] = out.get(k, 0.0) + v
+    return out

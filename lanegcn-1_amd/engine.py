@@ -229,9 +229,11 @@ class HotPathEngine:
             side.wait_stream(main)
         if side is None and self.fused_index and ops.index_fused_ok(fb.n_nodes, len(fb.rel_slices), sum(fb.n_edges)):
             # graph_gather (lanegcn.py:171-209) + CSR plan + the three pair searches: four launches in all
+            flag = torch.empty(1, dtype=torch.int32, device=dev)       # the range guard's flag, cleared by the first launch
             plan, pairs = ops.index_build(fb.idx_local, fb.seg_off, fb.seg_base, fb.rel_slices, fb.n_nodes, searches,
-                                          self.legacy_offsets, bufs=bufs, cnt=self._counters(fb))
+                                          self.legacy_offsets, bufs=bufs, cnt=self._counters(fb), clear_word=flag)
         else:
+            flag = torch.zeros(1, dtype=torch.int32, device=dev)
             with torch.cuda.stream(side if side is not None else main):
                 pairs = ops.pairs_build_multi(searches, self.legacy_offsets, bufs=bufs)   # three sets, three launches
             g64, _ = ops.graph_gather_indices(fb.idx_local, fb.seg_off, fb.seg_base)
@@ -270,7 +272,6 @@ class HotPathEngine:
         out["n_pairs"] = [p.n_pairs for p in pairs]
         # range check of the 16-bit-plane modes, on the device and part of every (captured) forward: bit 0 of
         # out["nonfinite"] is set when a feature row came out NaN / inf (ops.guarded / forward_guarded act on it)
-        flag = torch.zeros(1, dtype=torch.int32, device=feat.device)
         ops.check_finite(flag, feat, act)
         out["nonfinite"] = flag
         return out

@@ -874,13 +874,13 @@ def get_model():
     """The reference's plugin entry point (lanegcn.py:902-913; called by train.py:63-64, test.py:57):
     (config, Dataset, collate_fn, net, loss, post_process, opt)."""
     from .data import SyntheticArgoDataset
-    # The training loop of the reference is one Python thread per GPU (train.py:8-10, 175-186); with ~375 Python
-    # autograd Functions in a backward, running them on the calling thread instead of the engine's device thread
-    # saves 12 % of a step (43.5 -> 38.1 ms).  LGCN_AUTOGRAD_MT=1 keeps torch's default.
-    if os.environ.get("LGCN_AUTOGRAD_MT", "0") != "1":
-        torch.autograd.set_multithreading_enabled(False)
+    # Dataset: the reference returns its ArgoDataset (needs argoverse-api and the dataset, both absent here).  A caller
+    # that has them injects the class as config["dataset_cls"]; the synthetic generator is the explicit fallback and
+    # says so when it is handed a split path (data.SyntheticArgoDataset).  No process-wide switches are flipped here
+    # (train_dp.py turns off autograd's device thread for its own loop).
+    Dataset = config.get("dataset_cls") or SyntheticArgoDataset
     net = Net(config).cuda()
     loss = Loss(config).cuda()
     post_process = PostProcess(config).cuda()
     opt = Optimizer(net.parameters(), config)
-    return config, SyntheticArgoDataset, collate_fn, net, loss, post_process, opt
+    return config, Dataset, collate_fn, net, loss, post_process, opt

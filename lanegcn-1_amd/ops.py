@@ -320,10 +320,12 @@ def index_fused_ok(n_nodes: int, n_rel: int, n_edges_total: int) -> bool:
 
 
 def index_build(idx_local: torch.Tensor, seg_off: torch.Tensor, seg_base: torch.Tensor, rel_slices, n_nodes: int,
-                searches=(), legacy_offsets: bool = True, bufs=None, cnt: Optional[torch.Tensor] = None):
+                searches=(), legacy_offsets: bool = True, bufs=None, cnt: Optional[torch.Tensor] = None,
+                clear_word: Optional[torch.Tensor] = None):
     """graph_gather + CSR plan + the pair searches in four launches (lgcn_index_build).  rel_slices: per relation
     ((u_begin, u_end), (v_begin, v_end)) element ranges of idx_local.  cnt: index_counters() buffer owned by the caller
-    (all zero; comes back all zero); None: a fresh one per call (one extra fill launch).
+    (all zero; comes back all zero); None: a fresh one per call (one extra fill launch).  clear_word: an int32 device
+    word that the first launch sets to 0 (the forward's range-guard flag).
     Returns (LanePlan, [PairSet])."""
     lib = L.load()
     idx_local = _dev(idx_local, torch.int64, "idx_local")
@@ -353,6 +355,7 @@ def index_build(idx_local: torch.Tensor, seg_off: torch.Tensor, seg_base: torch.
     p.n_nodes = n_nodes
     p.rowptr, p.col, p.cnt, p.uv = rowptr.data_ptr(), col.data_ptr(), cnt.data_ptr(), uv.data_ptr()
     p.jobs, p.n_jobs = C.cast(jobs, C.c_void_p).value if len(searches) else 0, len(searches)
+    p.clear_word = 0 if clear_word is None else _dev(clear_word, torch.int32, "clear_word").data_ptr()
     L.check(lib.lgcn_index_build(C.byref(p), _stream()), "lgcn_index_build")
     plan = LanePlan(rowptr, col, n_rel, n_nodes, ne)
     plan.__dict__["_idx_keep"] = (cnt, uv, keep)       # alive until the plan is dropped (the launches are asynchronous)

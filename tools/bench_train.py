@@ -28,7 +28,7 @@ def main():
     if args.mma:
         ops.set_mma(args.mma)
     torch.manual_seed(0)
-    torch.autograd.set_multithreading_enabled(False)      # what get_model() does for the training loop
+    torch.autograd.set_multithreading_enabled(False)      # what train_dp.py does for its loop
     net = M.Net(M.config).cuda().train()
     loss_fn = M.Loss(M.config).cuda()
     opt = M.Optimizer(net.parameters(), M.config)

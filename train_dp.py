@@ -6,8 +6,10 @@ Kept from the reference (train.py:41-259): CLI flags -m/--model, --eval, --resum
 (:55-59); the model plugin call import_module(model).get_model() (:63-64); parameter broadcast from rank 0
 (:96,145); per-rank sampler shard with drop_last (:119-131); step order net -> loss -> post_process -> zero_grad ->
 backward -> [gradient average] -> opt.step(epoch) with epoch += 1/num_batches per iteration (:175-186); checkpoint
-dict {"epoch", "state_dict" (CPU tensors), "opt_state"} named "%3.3f.ckpt" (:230-242); display once per
-display_iters.  The gradient average is ONE flat all-reduce (lanegcn_amd.dist.allreduce_mean_grads).
+dict {"epoch", "state_dict" (CPU tensors), "opt_state"} named "%3.3f.ckpt" (:230-242) every save_iters; display +
+metrics reset every display_iters; a validation pass every val_iters and at the end (:189-208).  The gradient average
+is ONE flat all-reduce (lanegcn_amd.dist.allreduce_mean_grads).  Difference: the sampler drops the shard's tail
+where the reference's DistributedSampler pads it.
 """
 import argparse
 import os
@@ -86,15 +88,41 @@ def main(argv=None):
                 break
         return 0
 
+    # The reference runs its training loop on one Python thread per GPU (train.py:8-10, 175-186); with ~375 Python
+    # autograd Functions in a backward, running them on the calling thread instead of the engine's device thread
+    # saves 12 % of a step.  Scoped to this driver (LGCN_AUTOGRAD_MT=1 keeps torch's default).
+    if os.environ.get("LGCN_AUTOGRAD_MT", "0") != "1":
+        torch.autograd.set_multithreading_enabled(False)
+    val_set = Dataset(config.get("val_split"), config, train=False, **kw)
+
+    def validate(epoch):                                             # train.py:200-216
+        net.eval()
+        t_val, vm = time.time(), dict()
+        with torch.no_grad():
+            for vdata in batches(val_set, collate_fn, config["val_batch_size"], rank, world, 0, 0, shuffle=False):
+                vout = net(vdata)
+                post_process.append(vm, loss(vout, vdata), post_process(vout, vdata))
+        vm = D.gather_metrics(vm)
+        if rank == 0 and vm:
+            post_process.display(vm, time.time() - t_val, epoch)
+        net.train()
+
     net.train()
+    # The shard drops the tail that does not divide by the world size and by the batch size (the reference's
+    # DistributedSampler pads the shard by repeating samples, train.py:119-131; its DataLoader then drops the last
+    # partial batch): every rank sees the same number of full batches either way.
     per_rank = len(dataset) // world
-    num_batches = per_rank // config["batch_size"]
-    epoch = float(config["epoch"])
+    num_batches = max(per_rank // config["batch_size"], 1)
+    save_iters = int(np.ceil(config["save_freq"] * num_batches))                       # train.py:166-171
+    display_iters = max(int(config["display_iters"] / (world * config["batch_size"])), 1)
+    val_iters = max(int(config["val_iters"] / (world * config["batch_size"])), 1)
+    # a resumed epoch is a float accumulated in steps of 1 / num_batches: snap it to the batch grid before int()
+    epoch = round(float(config["epoch"]) * num_batches) / num_batches
     it, t0, metrics = 0, time.time(), dict()
-    last_path = None
-    for ep in range(int(epoch), config["num_epochs"]):
+    last_path, done = None, False
+    for ep in range(int(epoch + 0.5 / num_batches), config["num_epochs"]):
         for data in batches(dataset, collate_fn, config["batch_size"], rank, world, seed=0, epoch=ep):
-            epoch += 1.0 / max(num_batches, 1)
+            epoch += 1.0 / num_batches
             out = net(data)
             loss_out = loss(out, data)
             post_out = post_process(out, data)
@@ -104,13 +132,21 @@ def main(argv=None):
             D.allreduce_mean_grads(net.parameters())              # Horovod DistributedOptimizer semantics
             lr = opt.step(epoch)
             it += 1
-            if rank == 0 and (it % 10 == 0 or it == 1):
-                print("iter %d epoch %.3f lr %.5f loss %.4f (%.2f s)" % (it, epoch, lr, float(loss_out["loss"].detach()), time.time() - t0))
-            if args.max_iters and it >= args.max_iters:
+            num_iters = int(np.round(epoch * num_batches))
+            finished = epoch >= config["num_epochs"] or (args.max_iters and it >= args.max_iters)
+            if rank == 0 and (num_iters % save_iters == 0 or finished):                 # train.py:189-193
+                last_path = save_ckpt(net, opt, config["save_dir"], epoch)
+            if num_iters % display_iters == 0 or (args.max_iters and it % 10 == 0):      # train.py:195-201
+                metrics = D.gather_metrics(metrics)
+                if rank == 0:
+                    post_process.display(metrics, time.time() - t0, epoch, lr)
+                t0, metrics = time.time(), dict()
+            if num_iters % val_iters == 0 or finished:                                   # train.py:203-208
+                validate(epoch)
+            if finished:
+                done = True
                 break
-        if rank == 0:
-            last_path = save_ckpt(net, opt, config["save_dir"], epoch)
-        if args.max_iters and it >= args.max_iters:
+        if done:
             break
     D.barrier()
     if rank == 0 and last_path:
