@@ -351,6 +351,9 @@ class HotPathEngine:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.forward(fb, actors, **fwd_kw)
+        # a graph holds ADDRESSES: the captured inputs must outlive it (a freed FlatBatch's memory is handed to the next
+        # allocation, and the replay then builds its plan from whatever lies there)
+        graph._lgcn_inputs = (fb, actors)
         return graph, out
 
     def own_counters(self, fb: FlatBatch):
@@ -428,6 +431,7 @@ class FullNetEngine:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     out = self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
+            graph._lgcn_inputs = (fb, actor_feats, rot, orig)      # the graph holds their addresses: keep them alive
         finally:
             torch.backends.cudnn.benchmark = prev
         return graph, out

@@ -753,12 +753,9 @@ class Net(nn.Module):
             host = [0] + (torch.stack(out["n_pairs"]).flatten().tolist() if Att.strict else [])
         if Att.strict and any(int(c) == 0 for c in host[1:]):
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
-        cls, reg, st = [], [], 0
-        for a in sizes:
-            cls.append(out["cls"][st:st + a])
-            reg.append(out["reg"][st:st + a])
-            st += a
-        return {"cls": cls, "reg": reg}
+        # per-scene views in two calls (a Python slice per scene and tensor costs ~2 us each: 0.13 ms at batch 32)
+        sizes = [int(a) for a in sizes]
+        return {"cls": list(torch.split(out["cls"], sizes)), "reg": list(torch.split(out["reg"], sizes))}
 
 
 def _tree_cpu(x):

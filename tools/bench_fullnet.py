@@ -46,7 +46,7 @@ def main():
         fb = collate_flat(sc)
         feats, rot, orig = eng.actor_inputs(sc)
         g, _ = eng.capture(fb, feats, rot, orig, [len(s["ctrs"]) for s in sc])
-        lanes.append((torch.cuda.Stream(), g))
+        lanes.append((torch.cuda.Stream(), g))      # (capture() keeps fb / feats / rot / orig alive with the graph)
     for n_streams in (n_lanes,):
         steps = 100
         for i in range(20):
