@@ -208,7 +208,7 @@ __device__ __forceinline__ bool within(float ax, float ay, float cx, float cy, f
 template <int PASS>
 __device__ __forceinline__ void pairs_rows_body(const float2 *agt, const int32_t *agt_off,
                                                 const float2 *ctx, const int32_t *ctx_off,
-                                                int n_scenes, int n_agt, float th,
+                                                int n_scenes, int n_agt, int n_ctx, float th,
                                                 int32_t *rowcnt, const int32_t *rowptr,
                                                 const int32_t *hi_base, const int32_t *wi_base,
                                                 int32_t *hi, int32_t *wi, int64_t cap, int legacy,
@@ -217,7 +217,11 @@ __device__ __forceinline__ void pairs_rows_body(const float2 *agt, const int32_t
     const int g = row_block * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (g >= n_agt) return;
     const int sc = find_scene(agt_off, n_scenes, g);
-    const int c0 = ctx_off[sc], c1 = ctx_off[sc + 1];
+    // offset tables are caller data: a table that does not describe this job (stale memory under a captured graph)
+    // must not take a load or a store out of bounds
+    int c0 = ctx_off[sc], c1 = ctx_off[sc + 1];
+    c0 = c0 < 0 ? 0 : c0 > n_ctx ? n_ctx : c0;
+    c1 = c1 < c0 ? c0 : c1 > n_ctx ? n_ctx : c1;
     const float2 a = agt[g];
     int count = 0;
     int64_t pos = 0;
@@ -228,9 +232,13 @@ __device__ __forceinline__ void pairs_rows_body(const float2 *agt, const int32_t
         wbase = wi_base[sc] - c0;
         if (lane == 0) {
             const int P = rowptr[n_agt];
-            const bool advances = !legacy || rowptr[agt_off[sc + 1]] - rowptr[agt_off[sc]] > 0;
-            if (advances) rowptr_q[hval] = (int)pos;
-            else rowptr_q[hi_base[n_scenes] + g - hi_base[sc]] = P;
+            int s0 = agt_off[sc], s1 = agt_off[sc + 1];
+            s0 = s0 < 0 ? 0 : s0 > n_agt ? n_agt : s0;
+            s1 = s1 < s0 ? s0 : s1 > n_agt ? n_agt : s1;
+            const bool advances = !legacy || rowptr[s1] - rowptr[s0] > 0;
+            const int q2 = hi_base[n_scenes] + g - hi_base[sc];
+            if (advances) { if (hval >= 0 && hval <= n_agt) rowptr_q[hval] = (int)pos; }
+            else if (q2 >= 0 && q2 <= n_agt) rowptr_q[q2] = P;
             if (g == 0) rowptr_q[n_agt] = P;
         }
     }
@@ -259,7 +267,7 @@ __device__ __forceinline__ void pairs_rows_body(const float2 *agt, const int32_t
 struct PairsJob {
     const float2 *agt; const int32_t *agt_off;
     const float2 *ctx; const int32_t *ctx_off;
-    int n_scenes, n_agt, legacy;
+    int n_scenes, n_agt, n_ctx, legacy;
     float th;
     int32_t *hi, *wi;
     int64_t cap;
@@ -274,7 +282,7 @@ struct PairsJobs { PairsJob j[4]; };
 template <int PASS>
 __global__ __launch_bounds__(256) void k_pairs_rows(const PairsJobs jobs) {
     const PairsJob &j = jobs.j[blockIdx.y];
-    pairs_rows_body<PASS>(j.agt, j.agt_off, j.ctx, j.ctx_off, j.n_scenes, j.n_agt, j.th, j.rp(), j.rp(), j.hi_base(),
+    pairs_rows_body<PASS>(j.agt, j.agt_off, j.ctx, j.ctx_off, j.n_scenes, j.n_agt, j.n_ctx, j.th, j.rp(), j.rp(), j.hi_base(),
                           j.wi_base(), j.hi, j.wi, j.cap, j.legacy, j.rowptr_q, (int)blockIdx.x);
 }
 
@@ -311,7 +319,9 @@ __device__ __forceinline__ void pairs_scan_bases_body(int32_t *rp, int n_agt, co
         const int i = c + threadIdx.x;
         int th = 0, tw = 0;
         if (i < n_scenes) {
-            const int a0 = agt_off[i], a1 = agt_off[i + 1];
+            int a0 = agt_off[i], a1 = agt_off[i + 1];
+            a0 = a0 < 0 ? 0 : a0 > n_agt ? n_agt : a0;          // caller data: never index rp[] out of bounds
+            a1 = a1 < a0 ? a0 : a1 > n_agt ? n_agt : a1;
             const bool nonempty = rp[a1] - rp[a0] > 0;
             if (!legacy || nonempty) { th = a1 - a0; tw = ctx_off[i + 1] - ctx_off[i]; }
         }
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(256) void k_index_edges(const IndexParams p) {
         int jn = 0;
         while (jn + 1 < p.n_jobs && b >= p.job_blocks[jn + 1]) ++jn;
         const PairsJob &j = p.jobs.j[jn];
-        pairs_rows_body<PASS>(j.agt, j.agt_off, j.ctx, j.ctx_off, j.n_scenes, j.n_agt, j.th, j.rp(), j.rp(), j.hi_base(),
+        pairs_rows_body<PASS>(j.agt, j.agt_off, j.ctx, j.ctx_off, j.n_scenes, j.n_agt, j.n_ctx, j.th, j.rp(), j.rp(), j.hi_base(),
                               j.wi_base(), j.hi, j.wi, j.cap, j.legacy, j.rowptr_q, b - p.job_blocks[jn]);
         return;
     }
@@ -726,7 +736,7 @@ int lgcn_pairs_build_multi(const lgcn_pairs_job_t *jobs, int n_jobs, void *strea
         PairsJob &d = dj.j[k];
         d.agt = (const float2 *)q.agt_ctrs; d.agt_off = q.agt_off;
         d.ctx = (const float2 *)q.ctx_ctrs; d.ctx_off = q.ctx_off;
-        d.n_scenes = q.n_scenes; d.n_agt = (int)q.n_agt; d.legacy = q.legacy_offsets; d.th = q.dist_th;
+        d.n_scenes = q.n_scenes; d.n_agt = (int)q.n_agt; d.n_ctx = (int)q.n_ctx; d.legacy = q.legacy_offsets; d.th = q.dist_th;
         d.hi = q.hi; d.wi = q.wi; d.cap = q.cap; d.n_pairs = q.n_pairs; d.rowptr_q = q.rowptr; d.ws = q.ws;
         if (q.n_agt > max_rows) max_rows = q.n_agt;
     }
@@ -798,7 +808,7 @@ int lgcn_index_build(const lgcn_index_t *ph, void *stream) {
             PairsJob &d = p.jobs.j[k];
             d.agt = (const float2 *)jq.agt_ctrs; d.agt_off = jq.agt_off;
             d.ctx = (const float2 *)jq.ctx_ctrs; d.ctx_off = jq.ctx_off;
-            d.n_scenes = jq.n_scenes; d.n_agt = (int)jq.n_agt; d.legacy = jq.legacy_offsets; d.th = jq.dist_th;
+            d.n_scenes = jq.n_scenes; d.n_agt = (int)jq.n_agt; d.n_ctx = (int)jq.n_ctx; d.legacy = jq.legacy_offsets; d.th = jq.dist_th;
             d.hi = jq.hi; d.wi = jq.wi; d.cap = jq.cap; d.n_pairs = jq.n_pairs; d.rowptr_q = jq.rowptr; d.ws = jq.ws;
             p.job_blocks[k + 1] = p.job_blocks[k] + (int)((jq.n_agt + 3) / 4);
         } else {
