@@ -304,7 +304,9 @@ void k_lc_tile(const LcTileParams p) {
     const int kq = lane >> 4;
     const int item0 = xcd_chunk_remap(blockIdx.x, p.n_blocks * p.n_groups);
     const int b = item0 / p.n_groups, g = item0 % p.n_groups;
-    const int uend = p.gstart[g + 1];
+    // one unit group (finishing launch): the bounds sit at fixed argument offsets and travel with the first argument
+    // loads; several groups: a dynamically indexed argument is a scalar load of its own (one more round trip)
+    const int ubeg = FIN ? p.gstart[0] : p.gstart[g], uend = FIN ? p.gstart[1] : p.gstart[g + 1];
     constexpr bool finish = FIN;                       // n_groups == 1: this launch also runs GN -> ctr2 -> GN -> + X -> ReLU
     const LcLayout L(p.n_rows, M, p.cap);
     const int32_t *hdr = p.plan + L.hdr;
@@ -375,7 +377,7 @@ void k_lc_tile(const LcTileParams p) {
     asm volatile("" : "+s"(wreg[0]), "+s"(wreg[1]), "+s"(wreg[2]), "+s"(wreg[3]), "+s"(wreg[4]), "+s"(wreg[5]), "+s"(wreg[6]),
                  "+s"(wreg[7]), "+s"(wreg[8]), "+s"(wreg[9]), "+s"(wreg[10]), "+s"(wreg[11]), "+s"(wreg[12]), "+s"(wreg[13]),
                  "+s"(wreg[14]));      // one statement: the argument loads are issued together, one wait
-    for (int u0 = p.gstart[g]; u0 < uend;) {
+    for (int u0 = ubeg; u0 < uend;) {
         const int64_t item = (int64_t)b * kLcUnits + u0;
         const int4 h = *reinterpret_cast<const int4 *>(hdr + item * kLcHdr);
         const int4 hu = *reinterpret_cast<const int4 *>(hdr + item * kLcHdr + 4);
