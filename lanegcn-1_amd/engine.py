@@ -185,8 +185,7 @@ class HotPathEngine:
         self._side = None
         # the integer stage as lgcn_index_build (4 launches) instead of 12; False: the separate entry points
         self.fused_index = os.environ.get("LGCN_INDEX", "fused") == "fused"
-        self._cnt_capture = None      # counter buffer of the forward being captured (capture())
-        self._cnt_keep = []           # ... and of every graph captured so far (they live as long as the engine)
+        self._cnt_capture = None      # counter buffer of the forward being captured (capture(); it lives with the graph)
 
     def _counters(self, fb: FlatBatch) -> torch.Tensor:
         """Key counters of lgcn_index_build (zero before, zero after).  A captured forward owns a buffer of its own
@@ -347,28 +346,27 @@ class HotPathEngine:
                 self.forward(fb, actors, **fwd_kw)   # also fills the weight-pack caches outside the capture
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        with self.own_counters(fb):
+        with self.own_counters(fb) as cnt:
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self.forward(fb, actors, **fwd_kw)
-        # a graph holds ADDRESSES: the captured inputs must outlive it (a freed FlatBatch's memory is handed to the next
-        # allocation, and the replay then builds its plan from whatever lies there)
-        graph._lgcn_inputs = (fb, actors)
+        # a graph holds ADDRESSES: the captured inputs (and its counter buffer) must outlive it -- a freed FlatBatch's
+        # memory is handed to the next allocation, and the replay then builds its plan from whatever lies there
+        graph._lgcn_inputs = (fb, actors, cnt)
         return graph, out
 
     def own_counters(self, fb: FlatBatch):
-        """Context: forwards inside it use a fresh, zeroed counter buffer that stays alive with the engine -- for a
-        forward that is being captured (several captured forwards may replay concurrently)."""
+        """Context: forwards inside it use a fresh, zeroed counter buffer (yielded: keep it alive as long as what was
+        captured) -- for a forward that is being captured: several captured forwards may replay concurrently."""
         import contextlib
 
         @contextlib.contextmanager
         def cm():
             cnt = ops.index_counters(fb.n_nodes, len(fb.rel_slices), fb.node_ctrs.device)
             torch.cuda.synchronize()         # zeroed before anything captured can run
-            self._cnt_keep.append(cnt)
             prev, self._cnt_capture = self._cnt_capture, cnt
             try:
-                yield
+                yield cnt
             finally:
                 self._cnt_capture = prev
         return cm()
@@ -427,11 +425,11 @@ class FullNetEngine:
                     self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            with self.hot.own_counters(fb):
+            with self.hot.own_counters(fb) as cnt:
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     out = self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
-            graph._lgcn_inputs = (fb, actor_feats, rot, orig)      # the graph holds their addresses: keep them alive
+            graph._lgcn_inputs = (fb, actor_feats, rot, orig, cnt)      # the graph holds their addresses: keep them alive
         finally:
             torch.backends.cudnn.benchmark = prev
         return graph, out
