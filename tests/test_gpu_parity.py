@@ -409,6 +409,49 @@ def test_engine_matches_modules_and_graph_replay(hip, ref_state_names):
         assert np.array_equal(gout["nodes"].cpu().numpy(), want["m2m"]) and np.array_equal(gout["actors"].cpu().numpy(), want["a2a"])
 
 
+def test_captured_forwards_keep_their_inputs_and_counters(hip, ref_state_names):
+    """A hipGraph holds addresses, not references: capture() must keep the FlatBatch, the actor tensor and the index
+    counters of a captured forward alive.  Two lanes are captured, every outside reference to their inputs is dropped,
+    the freed memory is given to other tensors and overwritten -- the replays (one at a time and both in flight) must
+    still equal the eager forwards, and the counters must be zero afterwards."""
+    M, ops = hip
+    import gc
+    from lanegcn_amd import data as gen
+    from lanegcn_amd.engine import HotPathEngine, collate_flat
+    sd = O.seeded_state(ref_state_names, 5)
+    mods = {}
+    for name, cls in (("map_net", M.MapNet), ("a2m", M.A2M), ("m2m", M.M2M), ("m2a", M.M2A), ("a2a", M.A2A)):
+        m = cls(M.config)
+        m.load_state_dict({k[len(name) + 1:]: v for k, v in sd.items() if k.startswith(name + ".")})
+        mods[name] = m.cuda().eval()
+    eng = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"])
+    lanes, want = [], []
+    for j in range(2):
+        fb = collate_flat(gen.synth_batch("S2", seed=40 + j, n_scenes=4))
+        actors = torch.randn(fb.n_actors, 128, device="cuda").relu()
+        o = eng.forward(fb, actors)
+        want.append((o["nodes"].clone(), o["actors"].clone()))
+        g, out = eng.capture(fb, actors)
+        lanes.append((torch.cuda.Stream(), g, out))
+        del fb, actors, o
+    gc.collect()
+    torch.cuda.empty_cache()
+    junk = [torch.full((1 << 20,), -7, dtype=torch.int64, device="cuda") for _ in range(8)]      # lands on freed memory, if any
+    for st, g, out in lanes:
+        g.replay()
+        torch.cuda.synchronize()
+    for rep in range(6):
+        st, g, _ = lanes[rep % 2]
+        with torch.cuda.stream(st):
+            g.replay()
+    torch.cuda.synchronize()
+    for (st, g, out), (nodes, acts) in zip(lanes, want):
+        assert torch.allclose(out["nodes"], nodes, rtol=0, atol=1e-5) and torch.allclose(out["actors"], acts, rtol=0, atol=1e-5)
+        assert int(out["nonfinite"]) == 0
+        assert int(g._lgcn_inputs[-1].abs().sum()) == 0          # the graph's index counters came back to zero
+    del junk
+
+
 def test_full_net_engine_matches_net_forward(golden, ref_state_names, hip):
     """FullNetEngine (flat inputs, one hipGraph) == Net.forward on the reference's batch format."""
     M, _ = hip
