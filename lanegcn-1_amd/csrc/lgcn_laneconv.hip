@@ -21,16 +21,12 @@
 #include "lgcn_tile.hpp"
 #include "lgcn_mma_bf.hpp"
 
-#ifndef LGCN_V3_DBUF
-#define LGCN_V3_DBUF 0
-#endif
-
 namespace lgcn {
 
 constexpr int kLcUnits = LGCN_LC_UNITS;     // ctr + up to 14 lane relations
 constexpr int kLcHdr = 8;                   // int32 words per item header
 
-// Two workgroup shapes per operand format (Fmt<F>); V = 0 "shared": a short row block and a source-row capacity that
+// Three workgroup shapes per operand format (Fmt<F>); V = 0 "shared": a short row block and a source-row capacity that
 // keep the workgroup under half a CU (<= 78 KB of LDS, <= 128 VGPRs), so that two of them -- or one and another
 // stream's kernels -- share a CU and cover each other's loads and epilogues; V = 1 "tall": the whole CU, twice the
 // rows per weight byte, for batches with row blocks enough to fill the chip that way.
@@ -43,19 +39,15 @@ template <> struct LcCfg<1, 0> { static constexpr int RBN = 6, CAP = 144, HRB = 
 template <> struct LcCfg<1, 1> { static constexpr int RBN = 12, CAP = 304, HRB = 6; };
 template <> struct LcCfg<2, 0> { static constexpr int RBN = 6, CAP = 144, HRB = 2; };     // bf16  : 256 B
 template <> struct LcCfg<2, 1> { static constexpr int RBN = 12, CAP = 304, HRB = 6; };
-// V = 2 "short": one workgroup per CU for a single small forward that finishes the layer in ONE launch (all 15 units,
-// n_groups = 1): half the rows of the shared shape, so that ~2 x as many CUs work, every source row of the 15 units in
-// one item, a second weight register set so that the next unit's 64 KB slice streams in under this unit's MFMAs
-// (with <= 48 rows the L2 -> CU weight stream, not the matrix pipe, is what a unit costs).
-// V = 3 "short, shared": the short row block within the shared shape's budget (<= 128 VGPRs, <= 79 KB of LDS: CAP is the
-// most source rows a 48-row block of the S2 lane graphs names), so that TWO workgroups -- of one launch, or of two
-// forwards in flight -- share a CU and run their prologues / epilogues under each other's MFMA phases.
-template <> struct LcCfg<0, 3> { static constexpr int RBN = 2, CAP = 100, HRB = 2; };
-template <> struct LcCfg<1, 3> { static constexpr int RBN = 3, CAP = 156, HRB = 3; };
-template <> struct LcCfg<2, 3> { static constexpr int RBN = 3, CAP = 156, HRB = 3; };
-template <> struct LcCfg<0, 2> { static constexpr int RBN = 2, CAP = 112, HRB = 2; };
-template <> struct LcCfg<1, 2> { static constexpr int RBN = 3, CAP = 176, HRB = 3; };
-template <> struct LcCfg<2, 2> { static constexpr int RBN = 3, CAP = 176, HRB = 3; };
+// V = 2 "short": 48-row blocks (32 in three planes) within the shared shape's budget (<= 128 VGPRs, <= 79 KB of LDS:
+// CAP is the most source rows a 48-row block of the S2 lane graphs names): a small batch gives every CU one row block
+// that finishes the layer in ONE launch (all 15 units, n_groups = 1), and TWO workgroups -- of two forwards in flight
+// -- share a CU and run their prologues / epilogues under each other's MFMA phases.  (A 200-VGPR version of this shape
+// with a second weight set and A fragments two sub-blocks ahead was no faster alone and held a CU alone: removed,
+// DESIGN.md section 3.3b.)
+template <> struct LcCfg<0, 2> { static constexpr int RBN = 2, CAP = 100, HRB = 2; };
+template <> struct LcCfg<1, 2> { static constexpr int RBN = 3, CAP = 156, HRB = 3; };
+template <> struct LcCfg<2, 2> { static constexpr int RBN = 3, CAP = 156, HRB = 3; };
 
 // Plan buffer (int32 words).  Item (b, u0) = row block b, units u0 .. u0 + n_span - 1; slot b * 15 + u0.
 //   hdr  [n_blocks*15][8] : n_live, n_src, n_span, 0, then 16 bytes: the live (non-empty) units of the item
@@ -283,21 +275,18 @@ struct LcGeom {
     static constexpr int YR0 = 0, TOFF = HR * ROWB;
     static constexpr int EP_BYTES = TOFF + T2_BYTES, SRC_BYTES = (CAP + 1) * ROWB;
     static constexpr int SMEM = SRC_BYTES > EP_BYTES ? SRC_BYTES : EP_BYTES;
-    static_assert(RBN % HRB == 0 && SMEM <= (V == 0 ? 78 * 1024 - 256 : V == 1 ? 160 * 1024 - 256 : V == 2 ? 96 * 1024 : 80 * 1024 - 1024),
+    static_assert(RBN % HRB == 0 && SMEM <= (V == 0 ? 78 * 1024 - 256 : V == 1 ? 160 * 1024 - 256 : 80 * 1024 - 1024),
                   "row block does not fit the LDS");
 };
 
 template <int F, int V, bool FIN>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(V == 0 || V == 3 ? 4 : 2)))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(V == 1 ? 2 : 4)))
 void k_lc_tile(const LcTileParams p) {
     using G = LcGeom<F, V>;
     constexpr int RBN = G::RBN, CAP = G::CAP, NP = G::NP, ROWB = G::ROWB, M = G::M, HRB = G::HRB, HR = G::HR, PH = G::PH;
     constexpr int NIT = (CAP + 15) / 16;
-    constexpr bool DBUF = V == 1 || V == 2 || (V == 3 && LGCN_V3_DBUF);     // a second weight-slice register set
+    constexpr bool DBUF = V == 1;                      // tall: a second weight-slice register set (256 VGPRs to spend)
     constexpr int NLC = RBN > 8 ? 2 : 1;               // uint4 words of the per-row index
-    constexpr bool PIPE = V == 2;                      // short: A fragments requested NB - 1 sub-blocks ahead
-    constexpr int NB = RBN % 2 == 0 ? 2 : 3, PD = NB - 1;
-    static_assert(!PIPE || (RBN % NB == 0 && RBN >= PD && RBN <= 8), "pipelined unit loop: buffer index must be static");
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int cq = wave & 3, kh = wave >> 2;          // channel quarter, half of K
@@ -423,7 +412,6 @@ void k_lc_tile(const LcTileParams p) {
             load_w_ks(wptr(uf), wc, 0);
             load_w_ks(wptr(uf), wc, 1);
             load_loc(uf, lc);
-            if (PIPE && n_live > 1) load_loc(unit_at(1), ln);
         }
         // the zero row and (below) the unit list are written by EVERY thread, redundantly, rather than by the first
         // few lanes of wave 0: with partial-exec regions in this prologue the register allocator's spill reloads
@@ -438,7 +426,7 @@ void k_lc_tile(const LcTileParams p) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
                 if (it * 16 + hw >= n_src) e[it] = make_int2(0, -1);   // y < 0: no row
-            constexpr int NH = V == 2 ? NIT : DBUF ? (NIT + 1) / 2 : (NIT + 1) / 2 < 5 ? (NIT + 1) / 2 : 5;   // row loads in flight per lane (registers)
+            constexpr int NH = DBUF ? (NIT + 1) / 2 : (NIT + 1) / 2 < 5 ? (NIT + 1) / 2 : 5;   // row loads in flight per lane (registers)
 #pragma unroll
             for (int h0 = 0; h0 < NIT; h0 += NH) {
                 f32x4 v[NH];
@@ -476,70 +464,6 @@ void k_lc_tile(const LcTileParams p) {
         // behind the last unit of a finishing launch): tall shape -- fetched into a second register set while
         // this unit's MFMAs run; shared shape -- each K-step's registers are refilled as soon as the last
         // sub-block has used them (the co-resident workgroup covers what latency that leaves).
-        if constexpr (PIPE) {
-            // short shape.  The A fragments of a sub-block are requested PD sub-blocks ahead, across unit boundaries.
-            // The vector-issue port is what this loop is short of (an MFMA holds it for 8 of its 16 cycles, every
-            // other vector instruction for 4+), so a unit boundary moves no registers: units alternate between two
-            // weight sets and two row-index sets (the loop is unrolled by two), and the next unit's weight slice is
-            // requested in two halves between the MFMA groups.
-            uint4 A[NB][2][NP];
-            auto row_in = [&](const uint4 (&lo)[NLC], int rb) -> uint32_t {
-                const uint32_t w = rb < 2 ? lo[0].x : rb < 4 ? lo[0].y : rb < 6 ? lo[0].z : lo[0].w;
-                const uint32_t w16 = (w >> (16 * (rb & 1))) & 0xffffu;
-                return w16 == 0xffffu ? (uint32_t)CAP : w16;
-            };
-#pragma unroll
-            for (int d = 0; d < PD; ++d) {
-                rd(row_in(lc, d), 0, A[d][0]);
-                rd(row_in(lc, d), 1, A[d][1]);
-            }
-            auto unit = [&](int k, LcW<F> &wcur, LcW<F> &wnxt, uint4 (&lcur)[NLC], uint4 (&lnxt)[NLC]) {
-                // every request of a unit is unconditional (behind the last unit they fetch the second weight / re-read
-                // valid rows to no effect): with no branch in the loop the wait counters are exact
-                const float *wnext = k + 1 < n_live ? wptr(unit_at(k + 1)) : p.wp2;
-#pragma unroll
-                for (int rb = 0; rb < RBN; ++rb) {
-                    const int t = rb + PD;
-                    __builtin_amdgcn_sched_barrier(0);
-#ifdef LGCN_STAMPS
-                    if (!(p.exp & 1))
-#endif
-                    if (rb < 2) load_w_ks(wnext, wnxt, rb);
-#ifdef LGCN_STAMPS
-                    if (!(p.exp & 2)) {
-#endif
-                    if (t < RBN) {
-                        rd(row_in(lcur, t), 0, A[t % NB][0]);
-                        rd(row_in(lcur, t), 1, A[t % NB][1]);
-                    } else {
-                        rd(row_in(lnxt, t - RBN), 0, A[t % NB][0]);
-                        rd(row_in(lnxt, t - RBN), 1, A[t % NB][1]);
-                    }
-#ifdef LGCN_STAMPS
-                    }
-#endif
-                    // this unit's row index is dead behind its last own-row request: the index of the unit after
-                    // the next one lands there (needed one unit from now)
-                    if (rb == (RBN - PD > 0 ? RBN - PD - 1 : 0)) load_loc(unit_at(k + 2 < n_live ? k + 2 : n_live - 1), lcur);
-#ifdef LGCN_STAMPS
-                    if (p.exp & 4) continue;
-#endif
-                    __builtin_amdgcn_sched_barrier(0);
-                    mmw(acc[rb], 0, A[rb % NB][0], wcur);
-                    mmw(acc[rb], 1, A[rb % NB][1], wcur);
-#ifdef LGCN_STAMPS
-                    if ((p.exp & 16) && k < 6) LC_STAMP();
-#endif
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                LC_STAMP();   // unit k done
-            };
-            for (int k = 0; k < n_live; k += 2) {
-                unit(k, wc, wn, lc, ln);
-                if (k + 1 < n_live) unit(k + 1, wn, wc, ln, lc);
-            }
-            if (n_live & 1) wc = wn;      // the second weight (ctr2) is used from wc
-        } else
         for (int k = 0; k < n_live; ++k) {
             const bool more = k + 1 < n_live, tail2 = !more && last_item && finish;
             const int un = more ? unit_at(k + 1) : 0;
@@ -767,8 +691,8 @@ __global__ __launch_bounds__(256) void k_lc_combine(const LcCombParams p, int n_
 static int fmt_of(int mma) { return mma == LGCN_MMA_BF16X3 ? 0 : mma == LGCN_MMA_F16X2 ? 1 : 2; }
 
 static bool lc_cfg(int mma, int variant, int *M, int *cap) {
-    if (variant < 0 || variant > 3) return false;
-#define LGCN_CFG(F_) do { if (variant == 3) { *M = 16 * LcCfg<F_, 3>::RBN; *cap = LcCfg<F_, 3>::CAP; } else if (variant == 2) { *M = 16 * LcCfg<F_, 2>::RBN; *cap = LcCfg<F_, 2>::CAP; } else if (variant) { *M = 16 * LcCfg<F_, 1>::RBN; *cap = LcCfg<F_, 1>::CAP; } else { *M = 16 * LcCfg<F_, 0>::RBN; *cap = LcCfg<F_, 0>::CAP; } } while (0)
+    if (variant < 0 || variant > 2) return false;
+#define LGCN_CFG(F_) do { if (variant == 2) { *M = 16 * LcCfg<F_, 2>::RBN; *cap = LcCfg<F_, 2>::CAP; } else if (variant) { *M = 16 * LcCfg<F_, 1>::RBN; *cap = LcCfg<F_, 1>::CAP; } else { *M = 16 * LcCfg<F_, 0>::RBN; *cap = LcCfg<F_, 0>::CAP; } } while (0)
     switch (fmt_of(mma)) {
         case 0: LGCN_CFG(0); break;
         case 1: LGCN_CFG(1); break;
@@ -851,12 +775,10 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
     if (!lc_mma_ok(q.mma)) return LGCN_ESHAPE;
     const int M = q.rows_per_block;
     int variant = -1, capv = 0;
-    // the short shapes share their row-block height: the capacity tells them apart (a plan built for the shared one
-    // fits both; the larger budget is used only when the plan needs it)
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 3; ++v) {
         int Mv, cv;
         lc_cfg(q.mma, v, &Mv, &cv);
-        if (Mv == M && q.cap <= cv && (variant < 0 || cv < capv)) { variant = v; capv = cv; }
+        if (Mv == M) { variant = v; capv = cv; }
     }
     if (q.n_rows < 0 || variant < 0 || q.cap < M || q.cap > capv || q.n_rows > 0x7fffffff) return LGCN_EINVAL;
     if (!lc_groups_ok(q.n_units, q.n_groups, q.gstart)) return LGCN_EINVAL;
@@ -891,8 +813,7 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
     const int n_tiles = (int)((q.n_rows + 31) / 32);
 #define LGCN_LCV(F_, FIN_)                                                                                   \
     do {                                                                                                     \
-        if (variant == 3) hipLaunchKernelGGL((k_lc_tile<F_, 3, FIN_>), dim3(grid1), dim3(512), 0, st, t);     \
-        else if (variant == 2) hipLaunchKernelGGL((k_lc_tile<F_, 2, FIN_>), dim3(grid1), dim3(512), 0, st, t); \
+        if (variant == 2) hipLaunchKernelGGL((k_lc_tile<F_, 2, FIN_>), dim3(grid1), dim3(512), 0, st, t);     \
         else if (variant == 1) hipLaunchKernelGGL((k_lc_tile<F_, 1, FIN_>), dim3(grid1), dim3(512), 0, st, t); \
         else hipLaunchKernelGGL((k_lc_tile<F_, 0, FIN_>), dim3(grid1), dim3(512), 0, st, t);                  \
     } while (0)

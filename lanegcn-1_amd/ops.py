@@ -661,7 +661,7 @@ class LcPlan:
 
 
 def lc_config(mma: Optional[int] = None, variant: int = 0):
-    """(rows_per_block, LDS source-row capacity) of a matrix mode (variant 0: shared, 1: tall, 2: short, 3: short-shared);
+    """(rows_per_block, LDS source-row capacity) of a matrix mode (variant 0: shared, 1: tall, 2: short);
     None for LGCN_MMA_F32 (lgcn_agg_mlp path)."""
     lib = L.load()
     mma = _mma if mma is None else mma
@@ -694,8 +694,7 @@ _lc_variant_forced = int(os.environ.get("LGCN_LC_VARIANT", "-1"))
 
 
 def set_lc_variant(v: int):
-    """Force the row-block shape of subsequently built LaneConv plans (0 shared, 1 tall, 2 short, 3 short-shared,
-    -1 = pick by size)."""
+    """Force the row-block shape of subsequently built LaneConv plans (0 shared, 1 tall, 2 short, -1 = pick by size)."""
     global _lc_variant_forced
     _lc_variant_forced = int(v)
 
@@ -739,8 +738,8 @@ def lc_plan(lane: LanePlan, n_groups: Optional[int] = None, cap: Optional[int] =
             variant: Optional[int] = None) -> Optional[LcPlan]:
     """LaneConv work-item plan for the current matrix mode, built once per lane graph and cached on it.
     variant: 0 = shared (96-row blocks, two workgroups per CU), 1 = tall (192 rows, the whole CU), 2 = short (48 rows,
-    one launch per layer, the whole CU), 3 = short-shared (48 rows within the shared budget); default: short-shared
-    while its row blocks fit the CUs once, tall from two tall blocks per CU.
+    one launch per layer, within the shared budget); default: short while its row blocks fit the CUs once, tall from
+    two tall blocks per CU.
     n_groups: unit groups per row block (default 1: one launch per layer, no partial sums; more groups buy
     parallelism for a single small forward at the price of a second launch)."""
     if lc_config() is None:
@@ -751,12 +750,11 @@ def lc_plan(lane: LanePlan, n_groups: Optional[int] = None, cap: Optional[int] =
     if variant is None or variant < 0:
         cus = cu_count(lane.rowptr.device)
         m_tall, _ = lc_config(variant=1)
-        m_short, _ = lc_config(variant=3)
+        m_short, _ = lc_config(variant=2)
         if (lane.n_nodes + m_short - 1) // m_short <= cus:
-            # a small batch: one short row block per CU finishes the layer in one launch.  The short-SHARED shape
-            # (128 VGPRs, 79 KB of LDS: two workgroups per CU) is as fast as the short one for one forward and lets
-            # the layers of forwards in flight overlap (S2, four in flight: 125 k vs 115 k scenes/s)
-            variant = 3
+            # a small batch: one short row block per CU finishes the layer in one launch; the shape stays within
+            # 128 VGPRs / 79 KB of LDS, so the layers of forwards in flight overlap two per CU
+            variant = 2
         else:
             variant = 1 if (lane.n_nodes + m_tall - 1) // m_tall >= 2 * cus else 0
     M, cap_max = lc_config(variant=variant)
@@ -766,7 +764,7 @@ def lc_plan(lane: LanePlan, n_groups: Optional[int] = None, cap: Optional[int] =
         # one group (one launch per layer, no partial sums) once the row blocks alone fill the chip; small batches
         # buy parallelism with unit groups (S2, 108 short row blocks on 256 CUs: two groups)
         n_blocks = (lane.n_nodes + M - 1) // M
-        n_groups = _lc_groups_forced if _lc_groups_forced > 0 else 1 if variant in (2, 3) else max(1, min(4, round(cu_count(lane.rowptr.device) / max(n_blocks, 1))))
+        n_groups = _lc_groups_forced if _lc_groups_forced > 0 else 1 if variant == 2 else max(1, min(4, round(cu_count(lane.rowptr.device) / max(n_blocks, 1))))
     gstart = lc_groups(n_units, n_groups)
     cache = lane.__dict__.setdefault("_lc", {})
     key = (M, cap, tuple(gstart))

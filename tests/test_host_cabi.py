@@ -126,10 +126,10 @@ def test_unknown_flag_bits_and_laneconv_arguments(lib):
         assert l.lgcn_agg_mlp(C.byref(p), None) == EINVAL
     m, c = C.c_int32(), C.c_int32()
     assert l.lgcn_lc_config(mod.MMA_F32, 0, C.byref(m), C.byref(c)) == ESHAPE          # exact f32: lgcn_agg_mlp path
-    assert l.lgcn_lc_config(mod.MMA_F16X2, 4, C.byref(m), C.byref(c)) == EINVAL
+    assert l.lgcn_lc_config(mod.MMA_F16X2, 3, C.byref(m), C.byref(c)) == EINVAL
     geoms = {}
     for mma in (mod.MMA_BF16X3, mod.MMA_F16X2, mod.MMA_BF16):
-        for v in (0, 1, 2, 3):
+        for v in (0, 1, 2):
             assert l.lgcn_lc_config(mma, v, C.byref(m), C.byref(c)) == 0
             assert m.value % 16 == 0 and c.value >= m.value
             geoms[(mma, v)] = (m.value, c.value)

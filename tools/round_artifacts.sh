@@ -6,11 +6,10 @@ mkdir -p "$out"
 cd "$root"
 python bench.py > "$out/bench_s2.json" 2> "$out/bench_s2.err"
 echo "bench rc=$?"; tail -c 600 "$out/bench_s2.json" | head -c 300; echo
-python tools/stamps_lc.py 1 f16x2 32 3 2>&1 | grep -v amdgpu.ids > "$out/stamps_lc_tile_short_shared.txt"
 python tools/stamps_lc.py 1 f16x2 32 2 2>&1 | grep -v amdgpu.ids > "$out/stamps_lc_tile_short.txt"
 for w in a2a m2a a2m; do python tools/stamps_att.py $w 2>&1 | grep -v amdgpu.ids; done > "$out/stamps_att_pairs.txt"
-bash tools/pmc_lc.sh short_shared 1:3 > "$out/pmc.log" 2>&1
-cp gpurun_out/pmc_short_shared_counters.csv "$out/" 2>/dev/null
+bash tools/pmc_lc.sh short 1:2 > "$out/pmc.log" 2>&1
+cp gpurun_out/pmc_short_counters.csv "$out/" 2>/dev/null
 bash tools/prof_bench.sh prof_1s --streams 1 --steps 60 --warmup 5 --other-modes "" --no-extras > /dev/null 2>&1
 python tools/trace_summary.py gpurun_out/prof_1s/prof_1s_results.db 0.5 "$out/kernel_stats_bench_1stream.csv" > "$out/trace_1stream.txt"
 bash tools/prof_bench.sh prof_4s --steps 160 --warmup 10 --other-modes "" --no-extras > /dev/null 2>&1
