@@ -313,9 +313,11 @@ int lgcn_agg_mlp(const lgcn_agg_mlp_t *p_host, void *stream);
  * operands straight from the item's DISTINCT source rows, which it loads once into LDS.  lgcn_lc_plan_build lists
  * those rows once per batch (the lane graph is the same for the 8 LaneConv layers of a forward).
  *
- *   lgcn_lc_config      rows_per_block (variant 0: short row block, for batches that need the parallelism; variant 1:
- *                       tall, half the weight traffic per row) and the LDS source-row capacity of a matrix mode
- *                       (BF16X3 / F16X2 / BF16; F32 is not supported here: LGCN_ESHAPE, use lgcn_agg_mlp).
+ *   lgcn_lc_config      rows_per_block and the LDS source-row capacity of a shape in a matrix mode (BF16X3 / F16X2 /
+ *                       BF16; F32 is not supported here: LGCN_ESHAPE, use lgcn_agg_mlp).  variant 0 "shared": 96-row
+ *                       blocks (64 in BF16X3), two workgroups per CU; 1 "tall": 192 (128) rows, the whole CU, half
+ *                       the weight traffic per row, for batches with >= 2 such blocks per CU; 2 "short": 48 (32) rows
+ *                       within the shared budget: one block per CU finishes a small batch's layer in one launch.
  *   lgcn_lc_plan_build  rowptr / col: the lgcn_csr_build plan of n_rel relations (n_units = n_rel + 1 <= 15).
  *                       gstart_host[0..n_groups]: unit groups, gstart[0] = 0 < ... < gstart[n_groups] = n_units;
  *                       one workgroup per (row block, group).  n_groups = 1: a workgroup runs all units of its row
