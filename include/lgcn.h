@@ -151,6 +151,28 @@ int64_t lgcn_index_cnt_words(int64_t n_nodes, int n_rel);
 int lgcn_index_build(const lgcn_index_t *p_host, void *stream);
 
 /* ------------------------------------------------------------------ */
+/* ActorNet's convolution block           */
+/* ------------------------------------------------------------------ */
+
+/*
+ * layers.Conv1d / one half of layers.Res1d of the reference (layers.py:40-62, 142-190; ActorNet lanegcn.py:212-263)
+ * in one launch, on channels-last tensors:
+ *   out[a, l, :] = act( GN( sum_t W[:, :, t] x[a, l * stride + t - pad, :] ) + residual ),  pad = (ks - 1) / 2
+ * x [A, lin, cin] fp32, out [A, lout, cout], lout = (lin + 2 pad - ks) / stride + 1; GN = GroupNorm(1, cout): statistics
+ * over the lout x cout values of an actor (biased variance, eps), gamma / beta [cout].
+ * Supported: ks in {1, 3}, stride in {1, 2}, cin <= 128, cout in {32, 64, 128}, lout a divisor of 80 (ActorNet: 20, 10, 5);
+ * anything else: LGCN_ESHAPE.  wp: lgcn_conv_pack_weight image of W [cout, cin, ks] (lgcn_conv_packed_bytes bytes).
+ * res_mode 0: no residual; 1: res [A, lout, cout]; 2: res [A, lout / 2, cout], upsampled x2 as
+ * F.interpolate(mode = "linear", align_corners = False) (the FPN's top-down step, lanegcn.py:256-260).  relu != 0: ReLU last.
+ * Arithmetic: fp16 operand planes (2 planes, 3 products, fp32 accumulate: fp32-grade, |x|, |W| < 65504).
+ */
+int64_t lgcn_conv_packed_bytes(int cin, int cout, int ks);
+int lgcn_conv_pack_weight(const float *w, int cin, int cout, int ks, void *out, void *stream);
+int lgcn_conv1d_gn(const float *x, int64_t n_act, int lin, int cin, const void *wp, int cout, int ks, int stride,
+                   const float *gamma, const float *beta, float eps, const float *res, int res_mode, int relu,
+                   float *out, void *stream);
+
+/* ------------------------------------------------------------------ */
 /* Graph construction on the device       */
 /* ------------------------------------------------------------------ */
 

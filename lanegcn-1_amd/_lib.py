@@ -115,6 +115,9 @@ SIGNATURES = {
     "lgcn_check_finite": (C.c_int, [_P, _L, _P, _L, _P, _I, _P]),
     "lgcn_mapnet_input": (C.c_int, [_P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
     "lgcn_att_pairs": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _P, _P]),
+    "lgcn_conv_packed_bytes": (C.c_int64, [_I, _I, _I]),
+    "lgcn_conv_pack_weight": (C.c_int, [_P, _I, _I, _I, _P, _P]),
+    "lgcn_conv1d_gn": (C.c_int, [_P, _L, _I, _I, _P, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P, _P]),
     "lgcn_scan_ws_elems": (C.c_int64, [_L]),
     "lgcn_bool_square_bound": (C.c_int, [_P, _P, _L, _P, _P, _P]),
     "lgcn_bool_square": (C.c_int, [_P, _P, _L, _P, _P, _P, _P, _P]),

@@ -1,0 +1,322 @@
+// ActorNet's building block (reference layers.py:40-62 Conv1d, 142-190 Res1d; lanegcn.py:212-263) in ONE launch:
+//
+//   out[a, l, :] = act( GN_{(C, L) of actor a}( sum_t W_t x[a, l * stride + t - pad, :] ) + residual )
+//
+// on channels-last tensors x [A, Lin, Cin], out [A, Lout, Cout] (Lout = (Lin + 2 pad - K) / stride + 1, pad = (K - 1) / 2,
+// K = 1 or 3, stride = 1 or 2, Cin <= 128, Cout in {32, 64, 128}, GroupNorm with one group = statistics over all
+// Lout x Cout values of an actor).  residual: none | a tensor of the output's shape | a tensor of half the length,
+// upsampled x2 on the fly (F.interpolate(mode="linear", align_corners=False): the FPN's top-down step).
+//
+// A workgroup owns NA whole actors = 80 output rows (NA = 80 / Lout: 4, 8 or 16 actors at Lout = 20, 10, 5), so the
+// GroupNorm statistics never leave the CU.  The actors' input rows are staged once in LDS as fp16 operand planes
+// (2 planes, 3 products: the fp32-grade split of lgcn_mma_bf.hpp); the convolution is K x ceil(Cin / 32) MFMA K-steps
+// whose A fragments are the staged rows shifted by the tap (rows outside the sequence read an all-zero row); a wave
+// owns one 16-channel block of the output and a share of the five 16-row sub-blocks, its weight fragments come from
+// the packed image (lgcn_conv_pack_weight) once per K-step.  The 80 x Cout fp32 tile then goes through LDS to the
+// norm: 512 / NA threads per actor, two passes (mean, then variance about it, as ATen's GroupNorm), residual, ReLU, and
+// 512-byte coalesced stores.
+#include "lgcn_common.hpp"
+#include "lgcn_tile.hpp"
+#include "lgcn_mma_bf.hpp"
+
+namespace lgcn {
+
+constexpr int kConvRows = 80;          // output rows per workgroup (5 sub-blocks of 16)
+constexpr int kConvSub = kConvRows / 16;
+
+struct ConvParams {
+    const float *x;                    // [A, lin, cin]
+    int64_t n_act;
+    int lin, cin, cout, ks, stride, lout;
+    const uint4 *wp;                   // packed weight image
+    const float *gamma, *beta;
+    float eps;
+    const float *res;                  // residual source or null
+    int res_mode;                      // 0 none, 1 [A, lout, cout], 2 [A, lout / 2, cout] upsampled x2
+    int relu;
+    float *out;                        // [A, lout, cout]
+};
+
+__host__ __device__ inline int conv_kpad(int cin) { return (cin + 31) & ~31; }
+
+// Packed image: for tap t, K-chunk kc (32 input channels), channel block cb (16 outputs), plane pl: 64 x uint4, lane
+// (n = lane & 15, kq = lane >> 4) holds W[16 cb + n][32 kc + 8 kq + j][t], j = 0..7, as fp16 plane pl (hi, then the
+// rounding of the residual).  Input channels beyond cin are zero.
+__global__ __launch_bounds__(256) void k_conv_pack(const float *w, int cout, int cin, int ks, uint4 *out) {
+    const int nkc = conv_kpad(cin) / 32, ncb = cout / 16;
+    const int64_t total = (int64_t)ks * nkc * ncb * 64;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int lane = (int)(i & 63);
+    int64_t q = i >> 6;
+    const int cb = (int)(q % ncb); q /= ncb;
+    const int kc = (int)(q % nkc);
+    const int t = (int)(q / nkc);
+    const int n = lane & 15, kq = lane >> 4;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = 32 * kc + 8 * kq + j;
+        v[j] = c < cin ? w[((int64_t)(16 * cb + n) * cin + c) * ks + t] : 0.f;
+    }
+    uint32_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        hi[j] = Fmt<1>::pack(v[2 * j], v[2 * j + 1]);
+        const f32x2 r = Fmt<1>::unpack(hi[j]);
+        lo[j] = Fmt<1>::pack(v[2 * j] - r.x, v[2 * j + 1] - r.y);
+    }
+    const int64_t base = ((((int64_t)t * nkc + kc) * ncb + cb) * 2) << 6;
+    out[base + lane] = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+    out[base + 64 + lane] = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+}
+
+// F.interpolate(scale_factor = 2, mode = "linear", align_corners = False) of a length-n sequence at output position j:
+// source coordinate (j + 0.5) / 2 - 0.5, clamped at 0; weights 0.75 / 0.25 (and 1 / 0 at the two ends).
+__device__ __forceinline__ void up2_taps(int j, int n, int &i0, int &i1, float &w1) {
+    float src = (j + 0.5f) * 0.5f - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    i0 = (int)src;
+    i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+    w1 = src - (float)i0;
+}
+
+__global__ __launch_bounds__(512) void k_conv_gn(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = kConvRows / p.lout;                        // actors per workgroup
+    const int64_t a0 = (int64_t)blockIdx.x * na;
+    const int kpad = conv_kpad(p.cin), ldk = kpad + 8;         // fp16 elements per staged row (+ 16 B: bank spread)
+    const int n_in = na * p.lin;                               // staged input rows; row n_in is all zero
+    uint16_t *P0 = reinterpret_cast<uint16_t *>(smem);
+    uint16_t *P1 = P0 + (n_in + 1) * ldk;
+    const int ldt = p.cout + 4;
+    float *T = reinterpret_cast<float *>(smem);                // the fp32 tile takes the planes' place once the GEMM is done
+    const int pad = (p.ks - 1) >> 1;
+
+    // ---- stage the actors' input rows as two fp16 planes (4 channels per thread and step, four row loads in flight)
+    {
+        const int c4n = kpad / 4, total = (n_in + 1) * c4n;
+        for (int i0 = tid; i0 < total; i0 += 4 * 512) {
+            float4 v[4];
+            int rr[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 512;
+                const int r = i / c4n, c = 4 * (i - r * c4n);
+                rr[u] = r; cc[u] = c;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int ar = r / p.lin;
+                const int64_t a = a0 + ar;
+                if (i < total && r < n_in && a < p.n_act) {
+                    const float *src = p.x + (a * p.lin + (r - ar * p.lin)) * p.cin + c;
+                    if (c + 3 < p.cin && (p.cin & 3) == 0) v[u] = *reinterpret_cast<const float4 *>(src);
+                    else {
+                        if (c < p.cin) v[u].x = src[0];
+                        if (c + 1 < p.cin) v[u].y = src[1];
+                        if (c + 2 < p.cin) v[u].z = src[2];
+                        if (c + 3 < p.cin) v[u].w = src[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * 512 < total) {
+                    const uint32_t h0 = Fmt<1>::pack(v[u].x, v[u].y), h1 = Fmt<1>::pack(v[u].z, v[u].w);
+                    const f32x2 r0 = Fmt<1>::unpack(h0), r1 = Fmt<1>::unpack(h1);
+                    *reinterpret_cast<uint2 *>(P0 + rr[u] * ldk + cc[u]) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(P1 + rr[u] * ldk + cc[u]) =
+                        make_uint2(Fmt<1>::pack(v[u].x - r0.x, v[u].y - r0.y), Fmt<1>::pack(v[u].z - r1.x, v[u].w - r1.y));
+                }
+            }
+        }
+    }
+    lds_barrier();
+
+    // ---- convolution: wave -> channel block cb and the sub-blocks rb0, rb0 + nw, ...
+    const int ncb = p.cout >> 4, nw = 8 / ncb, nkc = kpad >> 5;
+    const int cb = wave % ncb, rb0 = wave / ncb;
+    const int kq = lane >> 4;
+    f32x4 acc[kConvSub];
+    int base[kConvSub], lpos[kConvSub];
+#pragma unroll
+    for (int i = 0; i < kConvSub; ++i) {
+        acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int r = 16 * (rb0 + i * nw) + (lane & 15);       // output row of this lane in sub-block i (may be >= 80: unused)
+        const int a = r / p.lout, l = r - a * p.lout;
+        base[i] = a * p.lin;
+        lpos[i] = l * p.stride - pad;
+    }
+    // weight fragments one K-step ahead (an L2 round trip is longer than a K-step's 15 MFMAs)
+    const int nks = p.ks * nkc;
+    auto wfrag = [&](int s_, uint4 &h, uint4 &l_) {
+        const int64_t wb = (((int64_t)s_ * ncb + cb) * 2) << 6;    // s_ = t * nkc + kc
+        h = p.wp[wb + lane];
+        l_ = p.wp[wb + 64 + lane];
+    };
+    uint4 nb0, nb1;
+    wfrag(0, nb0, nb1);
+    for (int t = 0; t < p.ks; ++t) {
+        int roff[kConvSub];                                     // LDS element offset of this lane's row under tap t
+#pragma unroll
+        for (int i = 0; i < kConvSub; ++i) {
+            const int li = lpos[i] + t;
+            roff[i] = ((li >= 0 && li < p.lin) ? base[i] + li : n_in) * ldk + 8 * kq;
+        }
+        for (int kc = 0; kc < nkc; ++kc) {
+            const uint4 b0 = nb0, b1 = nb1;
+            const int sn = t * nkc + kc + 1;
+            wfrag(sn < nks ? sn : nks - 1, nb0, nb1);
+#pragma unroll
+            for (int i = 0; i < kConvSub; ++i) {
+                if (rb0 + i * nw < kConvSub) {                 // wave-uniform
+                    const int off = roff[i] + 32 * kc;
+                    const uint4 a_hi = *reinterpret_cast<const uint4 *>(P0 + off);
+                    const uint4 a_lo = *reinterpret_cast<const uint4 *>(P1 + off);
+                    f32x4 c = acc[i];                           // smallest terms first; weights first: D^T, 4 channels per lane
+                    c = Fmt<1>::mfma(b0, a_lo, c);
+                    c = Fmt<1>::mfma(b1, a_hi, c);
+                    c = Fmt<1>::mfma(b0, a_hi, c);
+                    acc[i] = c;
+                }
+            }
+        }
+    }
+    lds_barrier();                                              // every wave is done reading the planes
+#pragma unroll
+    for (int i = 0; i < kConvSub; ++i)
+        if (rb0 + i * nw < kConvSub)
+            *reinterpret_cast<f32x4 *>(T + (16 * (rb0 + i * nw) + (lane & 15)) * ldt + 16 * cb + 4 * (lane >> 4)) = acc[i];
+    lds_barrier();
+
+    // ---- GroupNorm over (lout x cout) per actor, residual, ReLU.  All 512 threads: 512 / na threads per actor (128, 64
+    // or 32), each keeps its <= 5 float4 of the actor in registers (its channel quad is the same in every one of them:
+    // threads-per-actor is a multiple of cout / 4); the two statistics meet through 32-lane shuffles and one LDS word per
+    // half-wave.
+    __shared__ float s_red[2][16];
+    const int tpa = 512 / na, al = tid / tpa, j = tid - al * tpa;
+    const int c4 = p.cout >> 2, n4 = p.lout * c4;               // float4 columns per row, float4s per actor
+    const int64_t a = a0 + al;
+    const float *Ta = T + al * p.lout * ldt;
+    const int c = 4 * (j % c4);
+    float4 v[5];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int i = j + k * tpa;
+        v[k] = i < n4 ? *reinterpret_cast<const float4 *>(Ta + (i / c4) * ldt + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+    const float4 g = *reinterpret_cast<const float4 *>(p.gamma + c), bt = *reinterpret_cast<const float4 *>(p.beta + c);
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((tid & 31) == 0) s_red[0][tid >> 5] = s;
+    lds_barrier();
+    const int g0 = (al * tpa) >> 5, ng = tpa >> 5;              // this actor's half-waves
+    float mean = 0.f;
+    for (int k = 0; k < ng; ++k) mean += s_red[0][g0 + k];
+    const float per = (float)(p.lout * p.cout);
+    mean = mean / per;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        if (j + k * tpa < n4) {
+            const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+    if ((tid & 31) == 0) s_red[1][tid >> 5] = q;
+    lds_barrier();
+    float var = 0.f;
+    for (int k = 0; k < ng; ++k) var += s_red[1][g0 + k];
+    const float rstd = 1.0f / sqrtf(var / per + p.eps);
+    if (a < p.n_act) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = j + k * tpa;
+            if (i < n4) {
+                const int l = i / c4;
+                float4 y = make_float4((v[k].x - mean) * rstd * g.x + bt.x, (v[k].y - mean) * rstd * g.y + bt.y,
+                                       (v[k].z - mean) * rstd * g.z + bt.z, (v[k].w - mean) * rstd * g.w + bt.w);
+                if (p.res_mode == 1) {
+                    const float4 r = *reinterpret_cast<const float4 *>(p.res + (a * p.lout + l) * p.cout + c);
+                    y.x += r.x; y.y += r.y; y.z += r.z; y.w += r.w;
+                } else if (p.res_mode == 2) {
+                    int i0, i1;
+                    float w1;
+                    const int half = p.lout >> 1;
+                    up2_taps(l, half, i0, i1, w1);
+                    const float4 r0 = *reinterpret_cast<const float4 *>(p.res + (a * half + i0) * p.cout + c);
+                    const float4 r1 = *reinterpret_cast<const float4 *>(p.res + (a * half + i1) * p.cout + c);
+                    const float w0 = 1.0f - w1;
+                    y.x += w0 * r0.x + w1 * r1.x; y.y += w0 * r0.y + w1 * r1.y;
+                    y.z += w0 * r0.z + w1 * r1.z; y.w += w0 * r0.w + w1 * r1.w;
+                }
+                if (p.relu) { y.x = relu_nan(y.x); y.y = relu_nan(y.y); y.z = relu_nan(y.z); y.w = relu_nan(y.w); }
+                *reinterpret_cast<float4 *>(p.out + (a * p.lout + l) * p.cout + c) = y;
+            }
+        }
+    }
+}
+
+}  // namespace lgcn
+
+using namespace lgcn;
+
+extern "C" {
+
+static bool conv_shape_ok(int cin, int cout, int ks, int stride, int lin, int lout) {
+    if (cin < 1 || cin > 128 || (cout != 32 && cout != 64 && cout != 128)) return false;
+    if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2) || lin < 1) return false;
+    const int pad = (ks - 1) / 2;
+    if (lout != (lin + 2 * pad - ks) / stride + 1) return false;
+    return lout >= 1 && kConvRows % lout == 0 && lout <= kConvRows;
+}
+
+int64_t lgcn_conv_packed_bytes(int cin, int cout, int ks) {
+    if (cin < 1 || cin > 128 || (cout != 32 && cout != 64 && cout != 128) || (ks != 1 && ks != 3)) return LGCN_EINVAL;
+    return (int64_t)ks * (conv_kpad(cin) / 32) * (cout / 16) * 2 * 64 * 16;
+}
+
+int lgcn_conv_pack_weight(const float *w, int cin, int cout, int ks, void *out, void *stream) {
+    if (lgcn_conv_packed_bytes(cin, cout, ks) < 0) return LGCN_EINVAL;
+    LGCN_CHECK_PTR(w); LGCN_CHECK_PTR(out); LGCN_CHECK_ALIGN16(out);
+    const int64_t total = (int64_t)ks * (conv_kpad(cin) / 32) * (cout / 16) * 64;
+    hipLaunchKernelGGL(k_conv_pack, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, cout, cin, ks,
+                       reinterpret_cast<uint4 *>(out));
+    return launch_status();
+}
+
+int lgcn_conv1d_gn(const float *x, int64_t n_act, int lin, int cin, const void *wp, int cout, int ks, int stride,
+                   const float *gamma, const float *beta, float eps, const float *res, int res_mode, int relu,
+                   float *out, void *stream) {
+    if (n_act < 0 || res_mode < 0 || res_mode > 2) return LGCN_EINVAL;
+    const int pad = (ks - 1) / 2;
+    const int lout = stride > 0 ? (lin + 2 * pad - ks) / stride + 1 : 0;
+    if (!conv_shape_ok(cin, cout, ks, stride, lin, lout)) return LGCN_ESHAPE;
+    if (res_mode == 2 && (lout & 1)) return LGCN_ESHAPE;
+    if (n_act == 0) return LGCN_OK;
+    if (n_act > 0x7fffffff / (kConvRows * 128)) return LGCN_ESHAPE;
+    const void *al[] = {x, wp, gamma, beta, out};
+    for (const void *v : al) { LGCN_CHECK_PTR(v); LGCN_CHECK_ALIGN16(v); }
+    if (res_mode != 0) { LGCN_CHECK_PTR(res); LGCN_CHECK_ALIGN16(res); }
+    ConvParams p;
+    p.x = x; p.n_act = n_act; p.lin = lin; p.cin = cin; p.cout = cout; p.ks = ks; p.stride = stride; p.lout = lout;
+    p.wp = reinterpret_cast<const uint4 *>(wp); p.gamma = gamma; p.beta = beta; p.eps = eps;
+    p.res = res; p.res_mode = res_mode; p.relu = relu; p.out = out;
+    const int na = kConvRows / lout;
+    const size_t lds_planes = (size_t)2 * (na * lin + 1) * (conv_kpad(cin) + 8) * 2, lds_tile = (size_t)kConvRows * (cout + 4) * 4;
+    const size_t lds = lds_planes > lds_tile ? lds_planes : lds_tile;
+    if (lds > 160 * 1024) return LGCN_ESHAPE;
+    if (lds > 64 * 1024) {             // above the default ceiling of dynamic LDS (a property set on the code object; idempotent)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_gn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return (int)e;
+    }
+    const unsigned grid = (unsigned)((n_act + na - 1) / na);
+    hipLaunchKernelGGL(k_conv_gn, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -563,6 +563,46 @@ class ActorNet(nn.Module):
             out = gn(conv(lat.conv, pyramid[i]), lat.norm, res=out, res_up2=True)
         return res1d(self.output, out)[:, :, 0, -1]
 
+    def _forward_hip(self, actors: Tensor) -> Tensor:
+        """Inference path on lgcn_conv1d_gn: every Conv1d + GroupNorm (+ residual, + x2 upsampling, + ReLU) of the FPN is
+        ONE launch on [A, L, C] tensors: 20 launches instead of 20 stock convolutions + 20 norm launches."""
+        def cg(conv: nn.Conv1d, norm: nn.GroupNorm, x: Tensor, **kw) -> Tensor:
+            return ops.conv1d_gn(x, conv.weight, conv.stride[0], norm.weight, norm.bias, norm.eps, **kw)
+
+        def res1d(b: Res1d, x: Tensor) -> Tensor:
+            out = cg(b.conv1, b.bn1, x, relu=True)
+            skip = x if b.downsample is None else cg(b.downsample[0], b.downsample[1], x)
+            return cg(b.conv2, b.bn2, out, res=skip, relu=b.act)
+
+        out, pyramid = actors.transpose(1, 2).contiguous(), []          # [A, 3, 20] -> [A, 20, 3]
+        for g in self.groups:
+            for b in g:
+                out = res1d(b, out)
+            pyramid.append(out)
+        lat = self.lateral[-1]
+        out = cg(lat.conv, lat.norm, pyramid[-1], relu=lat.act)
+        for i in range(len(pyramid) - 2, -1, -1):
+            lat = self.lateral[i]
+            out = cg(lat.conv, lat.norm, pyramid[i], res=out, res_up2=True)
+        return res1d(self.output, out)[:, -1, :]
+
+    def _hip_ok(self, actors: Tensor) -> bool:
+        if ActorNet.impl != "hip" or not self._channels_last_ok(actors):
+            return False
+        convs = [c for g in self.groups for b in g for c in ([b.conv1, b.conv2] + ([b.downsample[0]] if b.downsample is not None else []))]
+        convs += [l.conv for l in self.lateral] + [self.output.conv1, self.output.conv2]
+        ok = all(c.bias is None and c.padding[0] == (c.kernel_size[0] - 1) // 2 and c.dilation[0] == 1 and c.groups == 1 for c in convs)
+        lens, lin = [], actors.shape[2]
+        for g in self.groups:                       # lengths along the FPN: stride-2 groups halve them
+            lin = (lin + 2 * 1 - 3) // g[0].conv1.stride[0] + 1
+            lens.append(lin)
+        return ok and all(80 % n == 0 for n in lens) and all(lens[i] == 2 * lens[i + 1] for i in range(len(lens) - 1)) and \
+            all(ops.conv_shape_ok(c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0], 20) or True for c in convs) and \
+            all(c.in_channels <= 128 and c.out_channels in (32, 64, 128) and c.kernel_size[0] in (1, 3) and c.stride[0] in (1, 2) for c in convs)
+
+    # "hip": lgcn_conv1d_gn launches; "miopen": stock channels-last convolutions + lgcn_gn_cl (LGCN_ACTORNET)
+    impl = os.environ.get("LGCN_ACTORNET", "hip")
+
     def _channels_last_ok(self, actors: Tensor) -> bool:
         mods = [b for g in self.groups for b in g] + [self.output]
         norms = [m for b in mods for m in (b.bn1, b.bn2)] + [l.norm for l in self.lateral]
@@ -572,6 +612,8 @@ class ActorNet(nn.Module):
                 and not any(l.act for l in self.lateral[:-1]))
 
     def forward(self, actors: Tensor) -> Tensor:
+        if self._hip_ok(actors):
+            return self._forward_hip(actors)
         if self._channels_last_ok(actors):
             return self._forward_channels_last(actors)
         pyramid, out = [], actors

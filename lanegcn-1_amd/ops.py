@@ -362,6 +362,54 @@ def index_build(idx_local: torch.Tensor, seg_off: torch.Tensor, seg_base: torch.
     return plan, pairs
 
 
+# ------------------------------------------------------------------ ActorNet's convolution block (row f1)
+def conv_shape_ok(cin: int, cout: int, ks: int, stride: int, lin: int) -> bool:
+    """Shapes lgcn_conv1d_gn takes (ActorNet's all do)."""
+    if cin < 1 or cin > 128 or cout not in (32, 64, 128) or ks not in (1, 3) or stride not in (1, 2) or lin < 1:
+        return False
+    lout = (lin + 2 * ((ks - 1) // 2) - ks) // stride + 1
+    return lout >= 1 and 80 % lout == 0
+
+
+def conv_packed(weight: torch.Tensor) -> torch.Tensor:
+    """Packed image of a Conv1d weight [cout, cin, ks] for lgcn_conv1d_gn, cached on the parameter."""
+    def make():
+        lib = L.load()
+        cout, cin, ks = weight.shape
+        nbytes = lib.lgcn_conv_packed_bytes(cin, cout, ks)
+        if nbytes < 0:
+            raise L.LgcnError("conv_packed: unsupported Conv1d weight shape %s" % (tuple(weight.shape),))
+        out = torch.empty(nbytes // 4, dtype=torch.int32, device=weight.device)
+        w = _dev(weight.detach(), torch.float32, "weight")
+        L.check(lib.lgcn_conv_pack_weight(_ptr(w), cin, cout, ks, _ptr(out), _stream()), "lgcn_conv_pack_weight")
+        return out
+    return _cached(weight, ("conv",), make)
+
+
+def conv1d_gn(x: torch.Tensor, weight: torch.Tensor, stride: int, gamma, beta, eps: float, res: Optional[torch.Tensor] = None,
+              res_up2: bool = False, relu: bool = False) -> torch.Tensor:
+    """Conv1d (k = 1 / 3, padding (k - 1) / 2, no bias) + GroupNorm(1, C) + residual + ReLU on channels-last tensors in one
+    launch (lgcn_conv1d_gn): x [A, L, Cin] -> [A, Lout, Cout]; res [A, Lout, Cout], or [A, Lout / 2, Cout] with res_up2."""
+    lib = L.load()
+    x = _dev(x, torch.float32, "x")
+    A_, lin, cin = x.shape
+    cout, cin_w, ks = weight.shape
+    if cin_w != cin:
+        raise L.LgcnError("conv1d_gn: weight does not match the input's channels")
+    lout = (lin + 2 * ((ks - 1) // 2) - ks) // stride + 1
+    out = torch.empty((A_, lout, cout), dtype=torch.float32, device=x.device)
+    mode = 0
+    if res is not None:
+        res = _dev(res, torch.float32, "res")
+        mode = 2 if res_up2 else 1
+        if tuple(res.shape) != ((A_, lout // 2, cout) if res_up2 else (A_, lout, cout)):
+            raise L.LgcnError("conv1d_gn: residual of the wrong shape")
+    L.check(lib.lgcn_conv1d_gn(_ptr(x), A_, lin, cin, _ptr(conv_packed(weight)), cout, ks, stride,
+                               _ptr(_dev(gamma.detach(), torch.float32, "gamma")), _ptr(_dev(beta.detach(), torch.float32, "beta")),
+                               float(eps), _ptr(res), mode, int(bool(relu)), _ptr(out), _stream()), "lgcn_conv1d_gn")
+    return out
+
+
 # ------------------------------------------------------------------ graph construction (row f3)
 def dilated_nbrs(u: torch.Tensor, v: torch.Tensor, num_nodes: int, num_scales: int):
     """Scales 1 .. num_scales - 1 of a relation on the device (reference data.dilated_nbrs, data.py:520-534): the

@@ -712,6 +712,63 @@ def test_actor_net_channels_last_path_equals_stock_path(hip):
     assert float((got - stock).abs().max()) <= 2e-4
 
 
+def test_actor_net_hip_conv_path(hip):
+    """ActorNet on lgcn_conv1d_gn (conv + GroupNorm + residual / x2-upsampled residual + ReLU in one launch) against the
+    CPU fp32 run of the same module and the channels-last stock path, actor counts that are not a multiple of the
+    workgroup's 4 / 8 / 16 actors included; and the single op against torch for every shape ActorNet uses."""
+    M, ops = hip
+    import torch.nn.functional as F
+    torch.manual_seed(13)
+    net = M.ActorNet(M.config).eval()
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() == 1:
+                p.uniform_(0.5, 1.5) if p.mean() > 0.5 else p.uniform_(-0.3, 0.3)
+    for n in (333, 1, 1600):
+        x = torch.randn(n, 3, 20) * 3.0
+        with torch.no_grad():
+            want = net(x)
+        net = net.cuda()
+        prev = M.ActorNet.impl
+        try:
+            with torch.no_grad():
+                M.ActorNet.impl = "hip"
+                assert net._hip_ok(x.cuda())
+                got = net(x.cuda())
+                M.ActorNet.impl = "miopen"
+                other = net(x.cuda())
+        finally:
+            M.ActorNet.impl = prev
+        net = net.cpu()
+        assert got.shape == (n, 128)
+        assert float((got.cpu() - want).abs().max()) <= 1e-4, n
+        assert float((got - other).abs().max()) <= 2e-4, n
+    # the op alone
+    gen = torch.Generator().manual_seed(3)
+    for cin, cout, ks, stride, lin, mode in ((3, 32, 3, 1, 20, 0), (3, 32, 1, 1, 20, 0), (32, 32, 3, 1, 20, 1), (32, 64, 3, 2, 20, 0),
+                                              (32, 64, 1, 2, 20, 0), (64, 64, 3, 1, 10, 1), (64, 128, 3, 2, 10, 0), (128, 128, 3, 1, 5, 1),
+                                              (64, 128, 3, 1, 10, 2), (32, 128, 3, 1, 20, 2), (128, 128, 3, 1, 20, 1)):
+        A_ = 37
+        x = torch.randn(A_, cin, lin, generator=gen)
+        w = torch.randn(cout, cin, ks, generator=gen) * (1.0 / (cin * ks) ** 0.5)
+        g, b = torch.rand(cout, generator=gen) + 0.5, torch.randn(cout, generator=gen) * 0.2
+        y = F.group_norm(F.conv1d(x, w, stride=stride, padding=(ks - 1) // 2), 1, g, b, 1e-5)
+        lout = y.shape[2]
+        res = None
+        if mode == 1:
+            res = torch.randn(A_, cout, lout, generator=gen)
+            y = y + res
+        elif mode == 2:
+            res = torch.randn(A_, cout, lout // 2, generator=gen)
+            y = y + F.interpolate(res, scale_factor=2, mode="linear", align_corners=False)
+        y = torch.relu(y)
+        wp = torch.nn.Parameter(w.cuda())
+        got = ops.conv1d_gn(x.transpose(1, 2).contiguous().cuda(), wp, stride, g.cuda(), b.cuda(), 1e-5,
+                            res=None if res is None else res.transpose(1, 2).contiguous().cuda(), res_up2=mode == 2, relu=True)
+        err = float((got.cpu().transpose(1, 2) - y).abs().max())
+        assert err <= 1e-4, (cin, cout, ks, stride, lin, mode, err)
+
+
 @pytest.mark.parametrize("shape", [(1600, 128, 20), (77, 32, 20), (9, 64, 10), (4, 128, 5), (3, 6, 4)])
 def test_gn_cl_channels_last_layout(hip, shape):
     """lgcn_gn_cl on [n, C, 1, L] channels_last tensors (memory [n, L, C]), incl. the upsampled residual, vs torch."""
