@@ -160,7 +160,7 @@ int lgcn_index_build(const lgcn_index_t *p_host, void *stream);
  *   out[a, l, :] = act( GN( sum_t W[:, :, t] x[a, l * stride + t - pad, :] ) + residual ),  pad = (ks - 1) / 2
  * x [A, lin, cin] fp32, out [A, lout, cout], lout = (lin + 2 pad - ks) / stride + 1; GN = GroupNorm(1, cout): statistics
  * over the lout x cout values of an actor (biased variance, eps), gamma / beta [cout].
- * Supported: ks in {1, 3}, stride in {1, 2}, cin <= 128, cout in {32, 64, 128}, lout a divisor of 80 (ActorNet: 20, 10, 5);
+ * Supported: ks in {1, 3}, stride in {1, 2}, cin <= 128, cout in {32, 64, 128}, lout in {5, 10, 20} (ActorNet's three pyramid levels);
  * anything else: LGCN_ESHAPE.  wp: lgcn_conv_pack_weight image of W [cout, cin, ks] (lgcn_conv_packed_bytes bytes).
  * res_mode 0: no residual; 1: res [A, lout, cout]; 2: res [A, lout / 2, cout], upsampled x2 as
  * F.interpolate(mode = "linear", align_corners = False) (the FPN's top-down step, lanegcn.py:256-260).  relu != 0: ReLU last.

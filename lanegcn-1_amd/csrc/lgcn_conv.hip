@@ -81,6 +81,7 @@ __device__ __forceinline__ void up2_taps(int j, int n, int &i0, int &i1, float &
     w1 = src - (float)i0;
 }
 
+template <int KS, int NKC>                                     // taps, 32-channel K chunks; KS == 0: both read from p (any shape)
 __global__ __launch_bounds__(512) void k_conv_gn(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -93,6 +94,24 @@ __global__ __launch_bounds__(512) void k_conv_gn(const ConvParams p) {
     const int ldt = p.cout + 4;
     float *T = reinterpret_cast<float *>(smem);                // the fp32 tile takes the planes' place once the GEMM is done
     const int pad = (p.ks - 1) >> 1;
+
+    // wave -> channel block cb and the row sub-blocks rb0, rb0 + nw, ...
+    const int ncb = p.cout >> 4, nw = 8 / ncb, nkc = KS ? NKC : kpad >> 5;
+    const int cb = wave % ncb, rb0 = wave / ncb;
+    const int kq = lane >> 4;
+    auto wfrag = [&](int s_, uint4 &h, uint4 &l_) {               // packed weight fragments of K-step s_ = t * nkc + kc
+        const int64_t wb = (((int64_t)s_ * ncb + cb) * 2) << 6;
+        h = p.wp[wb + lane];
+        l_ = p.wp[wb + 64 + lane];
+    };
+    // An L2 round trip is several K-steps long (a K-step is <= 15 MFMAs): with the shape known the first kWd steps'
+    // fragments are requested before the rows are staged and the ring is refilled kWd steps ahead.
+    constexpr int NKS = KS * NKC, kWd = NKS < 6 ? (NKS ? NKS : 1) : 6;
+    uint4 wh[kWd], wl[kWd];
+    if constexpr (KS != 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < kWd; ++s_) wfrag(s_, wh[s_], wl[s_]);
+    }
 
     // ---- stage the actors' input rows as two fp16 planes (4 channels per thread and step, four row loads in flight)
     {
@@ -133,10 +152,7 @@ __global__ __launch_bounds__(512) void k_conv_gn(const ConvParams p) {
     }
     lds_barrier();
 
-    // ---- convolution: wave -> channel block cb and the sub-blocks rb0, rb0 + nw, ...
-    const int ncb = p.cout >> 4, nw = 8 / ncb, nkc = kpad >> 5;
-    const int cb = wave % ncb, rb0 = wave / ncb;
-    const int kq = lane >> 4;
+    // ---- convolution
     f32x4 acc[kConvSub];
     int base[kConvSub], lpos[kConvSub];
 #pragma unroll
@@ -147,38 +163,48 @@ __global__ __launch_bounds__(512) void k_conv_gn(const ConvParams p) {
         base[i] = a * p.lin;
         lpos[i] = l * p.stride - pad;
     }
-    // weight fragments one K-step ahead (an L2 round trip is longer than a K-step's 15 MFMAs)
-    const int nks = p.ks * nkc;
-    auto wfrag = [&](int s_, uint4 &h, uint4 &l_) {
-        const int64_t wb = (((int64_t)s_ * ncb + cb) * 2) << 6;    // s_ = t * nkc + kc
-        h = p.wp[wb + lane];
-        l_ = p.wp[wb + 64 + lane];
-    };
-    uint4 nb0, nb1;
-    wfrag(0, nb0, nb1);
-    for (int t = 0; t < p.ks; ++t) {
-        int roff[kConvSub];                                     // LDS element offset of this lane's row under tap t
+    int roff[kConvSub];                                         // LDS element offset of this lane's row under the current tap
+    auto tap = [&](int t) {
 #pragma unroll
         for (int i = 0; i < kConvSub; ++i) {
             const int li = lpos[i] + t;
             roff[i] = ((li >= 0 && li < p.lin) ? base[i] + li : n_in) * ldk + 8 * kq;
         }
-        for (int kc = 0; kc < nkc; ++kc) {
-            const uint4 b0 = nb0, b1 = nb1;
-            const int sn = t * nkc + kc + 1;
-            wfrag(sn < nks ? sn : nks - 1, nb0, nb1);
+    };
+    auto kstep = [&](int kc, const uint4 b0, const uint4 b1) {
 #pragma unroll
-            for (int i = 0; i < kConvSub; ++i) {
-                if (rb0 + i * nw < kConvSub) {                 // wave-uniform
-                    const int off = roff[i] + 32 * kc;
-                    const uint4 a_hi = *reinterpret_cast<const uint4 *>(P0 + off);
-                    const uint4 a_lo = *reinterpret_cast<const uint4 *>(P1 + off);
-                    f32x4 c = acc[i];                           // smallest terms first; weights first: D^T, 4 channels per lane
-                    c = Fmt<1>::mfma(b0, a_lo, c);
-                    c = Fmt<1>::mfma(b1, a_hi, c);
-                    c = Fmt<1>::mfma(b0, a_hi, c);
-                    acc[i] = c;
-                }
+        for (int i = 0; i < kConvSub; ++i) {
+            if (rb0 + i * nw < kConvSub) {                     // wave-uniform
+                const int off = roff[i] + 32 * kc;
+                const uint4 a_hi = *reinterpret_cast<const uint4 *>(P0 + off);
+                const uint4 a_lo = *reinterpret_cast<const uint4 *>(P1 + off);
+                f32x4 c = acc[i];                               // smallest terms first; weights first: D^T, 4 channels per lane
+                c = Fmt<1>::mfma(b0, a_lo, c);
+                c = Fmt<1>::mfma(b1, a_hi, c);
+                c = Fmt<1>::mfma(b0, a_hi, c);
+                acc[i] = c;
+            }
+        }
+    };
+    if constexpr (KS != 0) {
+#pragma unroll
+        for (int s_ = 0; s_ < NKS; ++s_) {
+            if (s_ % NKC == 0) tap(s_ / NKC);
+            const uint4 b0 = wh[s_ % kWd], b1 = wl[s_ % kWd];
+            if (s_ + kWd < NKS) wfrag(s_ + kWd, wh[s_ % kWd], wl[s_ % kWd]);
+            kstep(s_ % NKC, b0, b1);
+        }
+    } else {
+        const int nks = p.ks * nkc;                             // any shape: fragments one K-step ahead
+        uint4 nb0, nb1;
+        wfrag(0, nb0, nb1);
+        for (int t = 0; t < p.ks; ++t) {
+            tap(t);
+            for (int kc = 0; kc < nkc; ++kc) {
+                const uint4 b0 = nb0, b1 = nb1;
+                const int sn = t * nkc + kc + 1;
+                wfrag(sn < nks ? sn : nks - 1, nb0, nb1);
+                kstep(kc, b0, b1);
             }
         }
     }
@@ -272,7 +298,7 @@ static bool conv_shape_ok(int cin, int cout, int ks, int stride, int lin, int lo
     if ((ks != 1 && ks != 3) || (stride != 1 && stride != 2) || lin < 1) return false;
     const int pad = (ks - 1) / 2;
     if (lout != (lin + 2 * pad - ks) / stride + 1) return false;
-    return lout >= 1 && kConvRows % lout == 0 && lout <= kConvRows;
+    return lout == 5 || lout == 10 || lout == 20;             // 16 / 8 / 4 actors per workgroup: 512 / na threads each in the GroupNorm phase
 }
 
 int64_t lgcn_conv_packed_bytes(int cin, int cout, int ks) {
@@ -309,13 +335,17 @@ int lgcn_conv1d_gn(const float *x, int64_t n_act, int lin, int cin, const void *
     const int na = kConvRows / lout;
     const size_t lds_planes = (size_t)2 * (na * lin + 1) * (conv_kpad(cin) + 8) * 2, lds_tile = (size_t)kConvRows * (cout + 4) * 4;
     const size_t lds = lds_planes > lds_tile ? lds_planes : lds_tile;
-    if (lds > 160 * 1024) return LGCN_ESHAPE;
+    if (lds > 159 * 1024) return LGCN_ESHAPE;                  // the kernel's static words share the 160 KB
+    void (*kern)(ConvParams) = k_conv_gn<0, 0>;
+    const int nkc = conv_kpad(cin) >> 5;
+    if (ks == 1) kern = nkc == 1 ? k_conv_gn<1, 1> : nkc == 2 ? k_conv_gn<1, 2> : nkc == 4 ? k_conv_gn<1, 4> : kern;
+    if (ks == 3) kern = nkc == 1 ? k_conv_gn<3, 1> : nkc == 2 ? k_conv_gn<3, 2> : nkc == 4 ? k_conv_gn<3, 4> : kern;
     if (lds > 64 * 1024) {             // above the default ceiling of dynamic LDS (a property set on the code object; idempotent)
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_conv_gn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         if (e != hipSuccess) return (int)e;
     }
     const unsigned grid = (unsigned)((n_act + na - 1) / na);
-    hipLaunchKernelGGL(k_conv_gn, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
     return launch_status();
 }
 

@@ -747,7 +747,8 @@ def test_actor_net_hip_conv_path(hip):
     gen = torch.Generator().manual_seed(3)
     for cin, cout, ks, stride, lin, mode in ((3, 32, 3, 1, 20, 0), (3, 32, 1, 1, 20, 0), (32, 32, 3, 1, 20, 1), (32, 64, 3, 2, 20, 0),
                                               (32, 64, 1, 2, 20, 0), (64, 64, 3, 1, 10, 1), (64, 128, 3, 2, 10, 0), (128, 128, 3, 1, 5, 1),
-                                              (64, 128, 3, 1, 10, 2), (32, 128, 3, 1, 20, 2), (128, 128, 3, 1, 20, 1)):
+                                              (64, 128, 3, 1, 10, 2), (32, 128, 3, 1, 20, 2), (128, 128, 3, 1, 20, 1),
+                                              (96, 64, 3, 1, 10, 1), (70, 32, 1, 2, 20, 0), (128, 128, 1, 1, 20, 0)):
         A_ = 37
         x = torch.randn(A_, cin, lin, generator=gen)
         w = torch.randn(cout, cin, ks, generator=gen) * (1.0 / (cin * ks) ** 0.5)

@@ -168,6 +168,35 @@ def test_unknown_flag_bits_and_laneconv_arguments(lib):
     assert l.lgcn_laneconv_fwd(C.byref(q), None) == 0                                    # no rows: no launch
 
 
+def test_conv_entry_points_validate_before_launching(lib):
+    """lgcn_conv1d_gn / lgcn_conv_pack_weight (ActorNet's blocks): sizes, shapes, pointers and alignment are checked on
+    the host before anything is launched."""
+    l, mod = lib
+    EINVAL, ESHAPE, EALIGN = -1, -2, -3
+    assert l.lgcn_conv_packed_bytes(128, 128, 3) == 3 * 4 * 8 * 2 * 64 * 16
+    assert l.lgcn_conv_packed_bytes(3, 32, 3) == 3 * 1 * 2 * 2 * 64 * 16           # K padded to one 32-channel chunk
+    assert l.lgcn_conv_packed_bytes(64, 128, 1) == 1 * 2 * 8 * 2 * 64 * 16
+    for cin, cout, ks in ((0, 32, 3), (129, 32, 3), (32, 48, 3), (32, 32, 2), (32, 32, 5)):
+        assert l.lgcn_conv_packed_bytes(cin, cout, ks) < 0
+        assert l.lgcn_conv_pack_weight(256, cin, cout, ks, 256, None) == EINVAL
+    assert l.lgcn_conv_pack_weight(None, 32, 32, 3, 256, None) == EINVAL
+    assert l.lgcn_conv_pack_weight(256, 32, 32, 3, 264, None) == EALIGN
+
+    def call(x=256, n=8, lin=20, cin=32, wp=256, cout=32, ks=3, stride=1, g=256, b=256, res=None, mode=0, out=256):
+        return l.lgcn_conv1d_gn(x, n, lin, cin, wp, cout, ks, stride, g, b, 1e-5, res, mode, 1, out, None)
+
+    assert call(n=0) == 0                                                            # nothing to do: no launch
+    assert call(n=-1) == EINVAL and call(mode=3) == EINVAL and call(mode=-1) == EINVAL
+    assert call(lin=8) == ESHAPE and call(lin=40) == ESHAPE                          # lout must be 5, 10 or 20
+    assert call(lin=20, stride=2, ks=1) != ESHAPE and call(stride=3) == ESHAPE and call(stride=0) == ESHAPE
+    assert call(cin=200) == ESHAPE and call(cout=96) == ESHAPE and call(ks=2) == ESHAPE
+    assert call(lin=10, stride=2, mode=2, res=256) == ESHAPE                          # x2 upsampling needs an even lout
+    assert call(x=None) == EINVAL and call(out=None) == EINVAL and call(g=None) == EINVAL
+    assert call(mode=1) == EINVAL and call(mode=1, res=260) == EALIGN                 # a residual mode needs its tensor
+    assert call(x=264) == EALIGN and call(wp=8) == EALIGN
+    assert call(n=1 << 40) == ESHAPE
+
+
 def test_shipped_library_reads_no_environment():
     """The tuning knobs (LGCN_RB, LGCN_RING, ...) and the work-skipping flag bits are compiled into the diagnostic
     builds only (make stamps / ablate): the product's kernel sources reach getenv only behind LGCN_TUNING."""
