@@ -173,6 +173,42 @@ int lgcn_conv1d_gn(const float *x, int64_t n_act, int lin, int cin, const void *
                    float *out, void *stream);
 
 /* ------------------------------------------------------------------ */
+/* PredNet's tail                         */
+/* ------------------------------------------------------------------ */
+
+/*
+ * The stock-op remainder of PredNet.forward (reference lanegcn.py:575-631), AttDest's first layer (lanegcn.py:725-729)
+ * and Net.forward's world-frame transform (lanegcn.py:147-150), inference.  The LinearRes / Linear + GroupNorm stages
+ * between the two calls are lgcn_agg_mlp row blocks.
+ *
+ * lgcn_pred_reg: for every mode m < n_mod (<= 8) and actor a
+ *   reg[a, m, :]  = w[m] h[m][a] + b[m] + (ctr[a].x, ctr[a].y, ctr[a].x, ...)     h[m] [A, 128], w[m] [np2, 128], b[m] [np2]
+ *   hd[a n_mod + m, :] = relu(wd (ctr[a] - reg[a, m, np2 - 2 : np2]) + bd)         wd [128, 2], bd [128]: AttDest.dist[0]
+ * np2 = 2 * num_preds, even, <= 64.  reg [A, n_mod, np2], hd [A n_mod, 128], ctrs [A, 2], all fp32.
+ */
+typedef struct lgcn_pred_reg {
+    const float *h[8];
+    const float *w[8];
+    const float *b[8];
+    const float *ctrs;
+    const float *wd, *bd;
+    float *reg, *hd;
+    int64_t n_act;
+    int32_t n_mod, np2;
+} lgcn_pred_reg_t;
+int lgcn_pred_reg(const lgcn_pred_reg_t *q, void *stream);
+
+/*
+ * lgcn_pred_final: scores cls[a, m] = wc . f[a n_mod + m, :] + bc (the nn.Linear(128, 1) of PredNet.cls), sorted
+ * descending per actor (equal scores keep mode order), reg's modes gathered in that order (lanegcn.py:614-625) and,
+ * when rot / orig are given ([A, 2, 2], [A, 2]: each actor's scene rotation and origin), taken to world coordinates:
+ * out[a, j, t, :] = reg[a, order_j, t, :] rot[a] + orig[a].  rot == orig == NULL: no transform.
+ * f [A n_mod, 128], reg / out [A, n_mod, n_pred, 2], cls [A, n_mod].
+ */
+int lgcn_pred_final(const float *f, const float *wc, const float *bc, const float *reg, const float *rot, const float *orig,
+                    int64_t n_act, int n_mod, int n_pred, float *cls, float *out, void *stream);
+
+/* ------------------------------------------------------------------ */
 /* Graph construction on the device       */
 /* ------------------------------------------------------------------ */
 

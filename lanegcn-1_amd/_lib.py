@@ -42,6 +42,14 @@ class Index(C.Structure):         # lgcn_index_t
     ]
 
 
+class PredReg(C.Structure):       # lgcn_pred_reg_t
+    _fields_ = [
+        ("h", C.c_void_p * 8), ("w", C.c_void_p * 8), ("b", C.c_void_p * 8),
+        ("ctrs", C.c_void_p), ("wd", C.c_void_p), ("bd", C.c_void_p), ("reg", C.c_void_p), ("hd", C.c_void_p),
+        ("n_act", C.c_int64), ("n_mod", C.c_int32), ("np2", C.c_int32),
+    ]
+
+
 class AggMlp(C.Structure):
     _fields_ = [
         ("n_rows", C.c_int64), ("n_rel", C.c_int32), ("n_rel_csr", C.c_int32),
@@ -118,6 +126,8 @@ SIGNATURES = {
     "lgcn_conv_packed_bytes": (C.c_int64, [_I, _I, _I]),
     "lgcn_conv_pack_weight": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "lgcn_conv1d_gn": (C.c_int, [_P, _L, _I, _I, _P, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P, _P]),
+    "lgcn_pred_reg": (C.c_int, [C.POINTER(PredReg), _P]),
+    "lgcn_pred_final": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "lgcn_scan_ws_elems": (C.c_int64, [_L]),
     "lgcn_bool_square_bound": (C.c_int, [_P, _P, _L, _P, _P, _P]),
     "lgcn_bool_square": (C.c_int, [_P, _P, _L, _P, _P, _P, _P, _P]),

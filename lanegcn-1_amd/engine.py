@@ -396,15 +396,18 @@ class FullNetEngine:
         actors = net.actor_net(actor_feats)
         hot = self.hot.forward(fb, actors)
         actors = hot["actors"]
-        idcs, ctrs, st = [], [], 0
-        for n in sizes:
-            idcs.append(slice(st, st + n))
-            ctrs.append(fb.actor_ctrs[st:st + n])
-            st += n
-        out = net.pred_net(actors, idcs, ctrs)
-        reg = torch.cat(out["reg"], 0)
-        cls = torch.cat(out["cls"], 0)
-        reg = torch.einsum("amtk,akj->amtj", reg, rot) + orig.view(-1, 1, 1, 2)
+        if net.pred_net._hip_ok(actors):
+            cls, reg = net.pred_net.forward_flat(actors, fb.actor_ctrs, rot, orig)     # world frame inside the last launch
+        else:
+            idcs, ctrs, st = [], [], 0
+            for n in sizes:
+                idcs.append(slice(st, st + n))
+                ctrs.append(fb.actor_ctrs[st:st + n])
+                st += n
+            out = net.pred_net(actors, idcs, ctrs)
+            reg = torch.cat(out["reg"], 0)
+            cls = torch.cat(out["cls"], 0)
+            reg = torch.einsum("amtk,akj->amtj", reg, rot) + orig.view(-1, 1, 1, 2)
         res = {"cls": cls, "reg": reg, "nonfinite": hot["nonfinite"]}
         ops.check_finite(hot["nonfinite"], reg.reshape(-1), cls.reshape(-1), bit=2)      # PredNet's row blocks too
         if return_pairs:

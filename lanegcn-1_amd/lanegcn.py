@@ -643,9 +643,14 @@ class AttDest(nn.Module):
         self.agt = Linear(2 * n_agt, n_agt, norm="GN", ng=1)
 
     def forward(self, agts: Tensor, agt_ctrs: Tensor, dest_ctrs: Tensor) -> Tensor:
-        n_agt, num_mods = agts.size(1), dest_ctrs.size(1)
+        num_mods = dest_ctrs.size(1)
         d = (agt_ctrs.unsqueeze(1) - dest_ctrs).reshape(-1, 2)
         h = F.relu(self.dist[0](d))                                   # nn.Linear(2,128): [rows,2]-shaped, stock op
+        return self.from_dist(agts, h, num_mods)
+
+    def from_dist(self, agts: Tensor, h: Tensor, num_mods: int) -> Tensor:
+        """The rest of forward() from h = relu(dist[0](agt_ctrs - dest_ctrs)) [A num_mods, n_agt]."""
+        n_agt = agts.size(1)
         a = agts.unsqueeze(1).expand(-1, num_mods, -1).reshape(-1, n_agt)
         if agts.is_cuda and n_agt == ops.C_FEAT:
             # dist.2 = Linear+GN+ReLU (one row block); agt = Linear(256 -> 128)+GN+ReLU over cat(dist, agts) = a
@@ -674,7 +679,30 @@ class PredNet(nn.Module):
         self.att_dest = AttDest(n)
         self.cls = nn.Sequential(LinearRes(n, n, norm="GN", ng=1), nn.Linear(n, 1))
 
+    impl = os.environ.get("LGCN_PREDNET", "hip")      # "hip": the stock-op tail on lgcn_pred_reg / lgcn_pred_final (inference)
+
+    def _hip_ok(self, actors: Tensor) -> bool:
+        cfg = self.config
+        return (PredNet.impl == "hip" and actors.is_cuda and actors.dtype == torch.float32 and actors.shape[0] > 0
+                and cfg["n_actor"] == ops.C_FEAT and cfg["num_mods"] <= 8 and 2 * cfg["num_preds"] <= 64
+                and not ops.wants_grad(actors, *ops.module_params(self)))
+
+    def forward_flat(self, actors: Tensor, ctrs: Tensor, rot: Optional[Tensor] = None, orig: Optional[Tensor] = None):
+        """Inference on the HIP tail: (cls [A, M] descending, reg [A, M, T, 2] in that order) for all actors of the batch;
+        with rot [A, 2, 2] / orig [A, 2] (each actor's scene rotation / origin) reg comes out in world coordinates
+        (Net.forward's loop, lanegcn.py:147-150).  Five launches besides the heads' row blocks: lgcn_pred_reg, AttDest's
+        two row blocks, the score head's LinearRes, lgcn_pred_final."""
+        actors = actors.contiguous()
+        h = [head[0](actors) for head in self.pred]                       # LinearRes row blocks
+        reg, hd = ops.pred_reg(h, [head[1].weight for head in self.pred], [head[1].bias for head in self.pred],
+                               ctrs, self.att_dest.dist[0].weight, self.att_dest.dist[0].bias)
+        f = self.cls[0](self.att_dest.from_dist(actors, hd, len(self.pred)))
+        return ops.pred_final(f, self.cls[1].weight, self.cls[1].bias, reg, rot, orig)
+
     def forward(self, actors: Tensor, actor_idcs: List[Tensor], actor_ctrs: List[Tensor]) -> Dict[str, List[Tensor]]:
+        if self._hip_ok(actors):
+            cls, reg = self.forward_flat(actors, torch.cat(actor_ctrs, 0))
+            return {"cls": [cls[i] for i in actor_idcs], "reg": [reg[i] for i in actor_idcs]}
         reg = torch.stack([head(actors) for head in self.pred], 1)
         reg = reg.view(reg.size(0), reg.size(1), -1, 2)
         ctrs = torch.cat(actor_ctrs, 0)

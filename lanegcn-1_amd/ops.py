@@ -5,7 +5,7 @@ without synchronising.  CPU tensors are rejected: the product path has no CPU fa
 """
 import ctypes as C
 from dataclasses import dataclass
-from typing import List, Optional, Sequence
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -408,6 +408,55 @@ def conv1d_gn(x: torch.Tensor, weight: torch.Tensor, stride: int, gamma, beta, e
                                _ptr(_dev(gamma.detach(), torch.float32, "gamma")), _ptr(_dev(beta.detach(), torch.float32, "beta")),
                                float(eps), _ptr(res), mode, int(bool(relu)), _ptr(out), _stream()), "lgcn_conv1d_gn")
     return out
+
+
+# ------------------------------------------------------------------ PredNet's tail (row f1)
+def pred_reg(h: Sequence[torch.Tensor], w: Sequence[torch.Tensor], b: Sequence[torch.Tensor], ctrs: torch.Tensor,
+             wd: torch.Tensor, bd: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """lgcn_pred_reg: reg [A, M, np2 / 2, 2] = w[m] h[m] + b[m] + ctr for the M heads, and AttDest's first layer
+    hd [A M, 128] = relu(wd (ctr - reg[:, :, -1]) + bd), in one launch."""
+    lib = L.load()
+    M, A_ = len(h), h[0].shape[0]
+    np2 = w[0].shape[0]
+    q = L.PredReg()
+    keep = []
+    for m in range(M):
+        hm, wm, bm = _dev(h[m], torch.float32, "h"), _dev(w[m].detach(), torch.float32, "w"), _dev(b[m].detach(), torch.float32, "b")
+        if tuple(hm.shape) != (A_, C_FEAT) or tuple(wm.shape) != (np2, C_FEAT) or tuple(bm.shape) != (np2,):
+            raise L.LgcnError("pred_reg: head %d has the wrong shape" % m)
+        keep += [hm, wm, bm]
+        q.h[m], q.w[m], q.b[m] = hm.data_ptr(), wm.data_ptr(), bm.data_ptr()
+    ctrs, wd, bd = _dev(ctrs, torch.float32, "ctrs"), _dev(wd.detach(), torch.float32, "wd"), _dev(bd.detach(), torch.float32, "bd")
+    if tuple(ctrs.shape) != (A_, 2) or tuple(wd.shape) != (C_FEAT, 2) or tuple(bd.shape) != (C_FEAT,):
+        raise L.LgcnError("pred_reg: ctrs / dist weight of the wrong shape")
+    reg = torch.empty((A_, M, np2 // 2, 2), dtype=torch.float32, device=ctrs.device)
+    hd = torch.empty((A_ * M, C_FEAT), dtype=torch.float32, device=ctrs.device)
+    keep += [ctrs, wd, bd]
+    q.ctrs, q.wd, q.bd, q.reg, q.hd = (t.data_ptr() for t in (ctrs, wd, bd, reg, hd))
+    q.n_act, q.n_mod, q.np2 = A_, M, np2
+    L.check(lib.lgcn_pred_reg(C.byref(q), _stream()), "lgcn_pred_reg")
+    return reg, hd
+
+
+def pred_final(f: torch.Tensor, wc: torch.Tensor, bc: torch.Tensor, reg: torch.Tensor, rot: Optional[torch.Tensor] = None,
+               orig: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """lgcn_pred_final: cls [A, M] (descending) = wc . f + bc and reg's modes in that order, taken to world coordinates
+    when rot [A, 2, 2] / orig [A, 2] are given."""
+    lib = L.load()
+    A_, M, npred, _ = reg.shape
+    f, reg = _dev(f, torch.float32, "f"), _dev(reg, torch.float32, "reg")
+    wc, bc = _dev(wc.detach().reshape(-1), torch.float32, "wc"), _dev(bc.detach(), torch.float32, "bc")
+    if tuple(f.shape) != (A_ * M, C_FEAT) or wc.numel() != C_FEAT or bc.numel() != 1:
+        raise L.LgcnError("pred_final: score head of the wrong shape")
+    if rot is not None:
+        rot, orig = _dev(rot, torch.float32, "rot"), _dev(orig, torch.float32, "orig")
+        if tuple(rot.shape) != (A_, 2, 2) or tuple(orig.shape) != (A_, 2):
+            raise L.LgcnError("pred_final: rot / orig of the wrong shape")
+    cls = torch.empty((A_, M), dtype=torch.float32, device=reg.device)
+    out = torch.empty_like(reg)
+    L.check(lib.lgcn_pred_final(_ptr(f), _ptr(wc), _ptr(bc), _ptr(reg), _ptr(rot), _ptr(orig), A_, M, npred,
+                                _ptr(cls), _ptr(out), _stream()), "lgcn_pred_final")
+    return cls, out
 
 
 # ------------------------------------------------------------------ graph construction (row f3)

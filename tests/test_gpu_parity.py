@@ -770,6 +770,80 @@ def test_actor_net_hip_conv_path(hip):
         assert err <= 1e-4, (cin, cout, ks, stride, lin, mode, err)
 
 
+def test_pred_net_hip_tail(hip):
+    """PredNet with its stock-op tail on lgcn_pred_reg / lgcn_pred_final against the CPU fp32 run of the same module
+    (scores, their order, the gathered trajectories), against the stock path on the device, and the world-frame
+    transform of the last launch against matmul + orig; the two ops alone against torch, equal scores included."""
+    M, ops = hip
+    torch.manual_seed(21)
+    net = M.PredNet(M.config).eval()
+    for n, sizes in ((333, (100, 33, 200)), (1, (1,)), (1600, (800, 800))):
+        actors = torch.randn(n, 128).relu()
+        ctrs = torch.randn(n, 2) * 30.0
+        idcs, cl, st = [], [], 0
+        for k in sizes:
+            idcs.append(torch.arange(st, st + k))
+            cl.append(ctrs[st:st + k])
+            st += k
+        with torch.no_grad():
+            want = net(actors, idcs, cl)
+        net = net.cuda()
+        prev = M.PredNet.impl
+        try:
+            with torch.no_grad():
+                M.PredNet.impl = "hip"
+                assert net._hip_ok(actors.cuda())
+                got = net(actors.cuda(), [i.cuda() for i in idcs], [c.cuda() for c in cl])
+                rot = torch.randn(n, 2, 2).cuda()
+                orig = (torch.randn(n, 2) * 100.0).cuda()
+                cls_w, reg_w = net.forward_flat(actors.cuda(), ctrs.cuda(), rot, orig)
+                M.PredNet.impl = "stock"
+                assert not net._hip_ok(actors.cuda())
+                other = net(actors.cuda(), [i.cuda() for i in idcs], [c.cuda() for c in cl])
+        finally:
+            M.PredNet.impl = prev
+        net = net.cpu()
+        for i in range(len(sizes)):
+            assert got["cls"][i].shape == want["cls"][i].shape and got["reg"][i].shape == want["reg"][i].shape
+            assert float((got["cls"][i].cpu() - want["cls"][i]).abs().max()) <= 1e-4
+            assert float((got["reg"][i].cpu() - want["reg"][i]).abs().max()) <= 1e-4
+            assert float((got["cls"][i] - other["cls"][i]).abs().max()) <= 1e-4
+            assert float((got["reg"][i] - other["reg"][i]).abs().max()) <= 1e-4
+        reg_all = torch.cat(got["reg"], 0)
+        ref_w = torch.matmul(reg_all.double(), rot.double().unsqueeze(1)) + orig.double().view(-1, 1, 1, 2)
+        assert float((reg_w.double() - ref_w).abs().max()) <= 1e-4 * 10       # values up to a few hundred: fp32 ulp 3e-5
+        assert torch.equal(cls_w, torch.cat(got["cls"], 0))
+    # the ops alone
+    gen = torch.Generator().manual_seed(5)
+    for A_, Mo, T in ((70, 6, 30), (33, 3, 7), (5, 8, 32)):
+        h = [torch.randn(A_, 128, generator=gen) for _ in range(Mo)]
+        w = [torch.randn(2 * T, 128, generator=gen) * 0.1 for _ in range(Mo)]
+        b = [torch.randn(2 * T, generator=gen) for _ in range(Mo)]
+        ctrs = torch.randn(A_, 2, generator=gen) * 10
+        wd, bd = torch.randn(128, 2, generator=gen), torch.randn(128, generator=gen)
+        reg = torch.stack([h[m].double() @ w[m].double().t() + b[m].double() for m in range(Mo)], 1).view(A_, Mo, T, 2) \
+            + ctrs.double().view(-1, 1, 1, 2)
+        hd = torch.relu((ctrs.double().unsqueeze(1) - reg[:, :, -1]).reshape(-1, 2) @ wd.double().t() + bd.double())
+        g_reg, g_hd = ops.pred_reg([t.cuda() for t in h], [t.cuda() for t in w], [t.cuda() for t in b], ctrs.cuda(), wd.cuda(), bd.cuda())
+        assert float((g_reg.cpu().double() - reg).abs().max()) <= 2e-5
+        assert float((g_hd.cpu().double() - hd).abs().max()) <= 2e-4
+        f = torch.randn(A_ * Mo, 128, generator=gen)
+        f[Mo:2 * Mo] = f[Mo]                                  # one actor with all scores equal: mode order is kept
+        wc, bc = torch.randn(1, 128, generator=gen), torch.randn(1, generator=gen)
+        cls = (f.double() @ wc.double().t() + bc.double()).view(A_, Mo)
+        scls, order = cls.sort(dim=1, descending=True, stable=True)
+        rot, orig = torch.randn(A_, 2, 2, generator=gen), torch.randn(A_, 2, generator=gen) * 50
+        regf = g_reg.cpu()
+        want = torch.matmul(torch.gather(regf.double(), 1, order.view(A_, Mo, 1, 1).expand(-1, -1, T, 2)), rot.double().unsqueeze(1)) \
+            + orig.double().view(-1, 1, 1, 2)
+        g_cls, g_out = ops.pred_final(f.cuda(), wc.cuda(), bc.cuda(), g_reg, rot.cuda(), orig.cuda())
+        assert float((g_cls.cpu().double() - scls).abs().max()) <= 2e-5
+        assert float((g_out.cpu().double() - want).abs().max()) <= 1e-4
+        g_cls2, g_out2 = ops.pred_final(f.cuda(), wc.cuda(), bc.cuda(), g_reg)
+        assert torch.equal(g_cls2, g_cls)
+        assert torch.equal(g_out2.cpu(), torch.gather(regf, 1, order.view(A_, Mo, 1, 1).expand(-1, -1, T, 2)))
+
+
 @pytest.mark.parametrize("shape", [(1600, 128, 20), (77, 32, 20), (9, 64, 10), (4, 128, 5), (3, 6, 4)])
 def test_gn_cl_channels_last_layout(hip, shape):
     """lgcn_gn_cl on [n, C, 1, L] channels_last tensors (memory [n, L, C]), incl. the upsampled residual, vs torch."""

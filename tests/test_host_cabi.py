@@ -197,6 +197,43 @@ def test_conv_entry_points_validate_before_launching(lib):
     assert call(n=1 << 40) == ESHAPE
 
 
+def test_pred_tail_entry_points_validate_before_launching(lib):
+    """lgcn_pred_reg / lgcn_pred_final (PredNet's tail): mode and horizon limits, pointers and alignment."""
+    l, mod = lib
+    EINVAL, ESHAPE, EALIGN = -1, -2, -3
+
+    def reg(n_act=10, n_mod=6, np2=60, **kw):
+        q = mod.PredReg()
+        for m in range(8):
+            q.h[m], q.w[m], q.b[m] = 256, 256, 256
+        q.ctrs, q.wd, q.bd, q.reg, q.hd = 256, 256, 256, 256, 256
+        q.n_act, q.n_mod, q.np2 = n_act, n_mod, np2
+        for k, v in kw.items():
+            if isinstance(v, tuple):
+                getattr(q, k)[v[0]] = v[1]
+            else:
+                setattr(q, k, v)
+        return l.lgcn_pred_reg(C.byref(q), None)
+
+    assert l.lgcn_pred_reg(None, None) == EINVAL
+    assert reg(n_act=0) == 0
+    assert reg(n_mod=0) == EINVAL and reg(n_mod=9) == EINVAL and reg(n_act=-1) == EINVAL
+    assert reg(np2=66) == ESHAPE and reg(np2=59) == ESHAPE and reg(np2=0) == ESHAPE
+    assert reg(h=(3, None)) == EINVAL and reg(w=(5, None)) == EINVAL and reg(b=(0, None)) == EINVAL
+    assert reg(h=(2, 260)) == EALIGN and reg(hd=264) == EALIGN and reg(wd=260) == EALIGN
+    assert reg(ctrs=None) == EINVAL and reg(reg=None) == EINVAL
+
+    def fin(f=256, wc=256, bc=256, reg_=256, rot=None, orig=None, n=0, m=6, t=30, cls=256, out=256):
+        return l.lgcn_pred_final(f, wc, bc, reg_, rot, orig, n, m, t, cls, out, None)
+
+    assert fin() == 0
+    assert fin(m=0) == EINVAL and fin(m=9) == EINVAL and fin(t=0) == EINVAL and fin(n=-1) == EINVAL
+    assert fin(t=5000) == ESHAPE
+    assert fin(f=None) == EINVAL and fin(cls=None) == EINVAL
+    assert fin(rot=256) == EINVAL and fin(orig=256) == EINVAL          # both or neither
+    assert fin(rot=264, orig=256) == EALIGN and fin(reg_=260) == EALIGN and fin(out=260) == EALIGN
+
+
 def test_shipped_library_reads_no_environment():
     """The tuning knobs (LGCN_RB, LGCN_RING, ...) and the work-skipping flag bits are compiled into the diagnostic
     builds only (make stamps / ablate): the product's kernel sources reach getenv only behind LGCN_TUNING."""
