@@ -690,10 +690,15 @@ class PredNet(nn.Module):
     def forward_flat(self, actors: Tensor, ctrs: Tensor, rot: Optional[Tensor] = None, orig: Optional[Tensor] = None):
         """Inference on the HIP tail: (cls [A, M] descending, reg [A, M, T, 2] in that order) for all actors of the batch;
         with rot [A, 2, 2] / orig [A, 2] (each actor's scene rotation / origin) reg comes out in world coordinates
-        (Net.forward's loop, lanegcn.py:147-150).  Five launches besides the heads' row blocks: lgcn_pred_reg, AttDest's
-        two row blocks, the score head's LinearRes, lgcn_pred_final."""
+        (Net.forward's loop, lanegcn.py:147-150).  Launches: the heads' row blocks (two per launch), lgcn_pred_reg,
+        AttDest's two row blocks, the score head's LinearRes, lgcn_pred_final."""
         actors = actors.contiguous()
-        h = [head[0](actors) for head in self.pred]                       # LinearRes row blocks
+        kws = [head[0].block_kw(actors) for head in self.pred]            # the heads' LinearRes row blocks, two per launch
+        h = []
+        for i in range(0, len(kws) - 1, 2):
+            h += list(ops.agg_mlp_pair(kws[i], kws[i + 1]))
+        if len(kws) % 2:
+            h.append(ops.agg_mlp(**kws[-1]))
         reg, hd = ops.pred_reg(h, [head[1].weight for head in self.pred], [head[1].bias for head in self.pred],
                                ctrs, self.att_dest.dist[0].weight, self.att_dest.dist[0].bias)
         f = self.cls[0](self.att_dest.from_dist(actors, hd, len(self.pred)))

@@ -148,6 +148,13 @@ class LinearRes(nn.Module):
                 and self.linear1.out_features == ops.C_FEAT and isinstance(self.norm1, nn.GroupNorm)
                 and self.norm1.num_groups == 1)
 
+    def block_kw(self, x):
+        """Keywords of the inference row block (ops.agg_mlp / one half of ops.agg_mlp_pair) for a contiguous x."""
+        full = L.F_GN1 | L.F_RELU1 | L.F_GEMM2 | L.F_GN2 | L.F_RES | L.F_RELU2
+        return dict(n_rows=x.shape[0], rels=[ops.RelSpec(x, ops.packed(self.linear1.weight))], flags=full,
+                    gn1=(self.norm1.weight, self.norm1.bias), wp2=ops.packed(self.linear2.weight),
+                    gn2=(self.norm2.weight, self.norm2.bias), res=x, eps=self.norm1.eps)
+
     def forward(self, x):
         if self._hot_shaped(x):
             # 128 -> 128: the fused two-stage row block of the hot path (one launch; PredNet heads, lanegcn.py:587-600)
@@ -158,10 +165,7 @@ class LinearRes(nn.Module):
                                    eps=self.norm1.eps)
                 return A.LaneConvFn.apply(spec, x, self.norm1.weight, self.norm1.bias, self.linear2.weight,
                                           self.norm2.weight, self.norm2.bias, self.linear1.weight)
-            full = L.F_GN1 | L.F_RELU1 | L.F_GEMM2 | L.F_GN2 | L.F_RES | L.F_RELU2
-            return ops.agg_mlp(x.shape[0], [ops.RelSpec(x, ops.packed(self.linear1.weight))], full,
-                               gn1=(self.norm1.weight, self.norm1.bias), wp2=ops.packed(self.linear2.weight),
-                               gn2=(self.norm2.weight, self.norm2.bias), res=x, eps=self.norm1.eps)
+            return ops.agg_mlp(**self.block_kw(x))
         out = group_norm1(self.linear1(x), self.norm1, relu=True)
         out = group_norm1(self.linear2(out), self.norm2)
         if self.transform is not None:
