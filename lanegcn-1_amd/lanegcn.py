@@ -584,7 +584,7 @@ class ActorNet(nn.Module):
         for i in range(len(pyramid) - 2, -1, -1):
             lat = self.lateral[i]
             out = cg(lat.conv, lat.norm, pyramid[i], res=out, res_up2=True)
-        return res1d(self.output, out)[:, -1, :]
+        return res1d(self.output, out)[:, -1, :].contiguous()        # a view would be copied again by every op that takes it
 
     def _hip_ok(self, actors: Tensor) -> bool:
         if ActorNet.impl != "hip" or not self._channels_last_ok(actors):
@@ -596,8 +596,8 @@ class ActorNet(nn.Module):
         for g in self.groups:                       # lengths along the FPN: stride-2 groups halve them
             lin = (lin + 2 * 1 - 3) // g[0].conv1.stride[0] + 1
             lens.append(lin)
-        return ok and all(80 % n == 0 for n in lens) and all(lens[i] == 2 * lens[i + 1] for i in range(len(lens) - 1)) and \
-            all(ops.conv_shape_ok(c.in_channels, c.out_channels, c.kernel_size[0], c.stride[0], 20) or True for c in convs) and \
+        # every level's length is one lgcn_conv1d_gn takes (5, 10, 20), consecutive levels halve (the x2 upsampling)
+        return ok and all(n in (5, 10, 20) for n in lens) and all(lens[i] == 2 * lens[i + 1] for i in range(len(lens) - 1)) and \
             all(c.in_channels <= 128 and c.out_channels in (32, 64, 128) and c.kernel_size[0] in (1, 3) and c.stride[0] in (1, 2) for c in convs)
 
     # "hip": lgcn_conv1d_gn launches; "miopen": stock channels-last convolutions + lgcn_gn_cl (LGCN_ACTORNET)
