@@ -4,6 +4,11 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out="$root/gpurun_out/final"
 mkdir -p "$out"
 cd "$root"
+# the stamp timelines come from the diagnostic build: it must be at least as new as the shipped library
+if [ ! -f lanegcn-1_amd/liblgcn_stamps.so ] || [ lanegcn-1_amd/liblgcn_stamps.so -ot lanegcn-1_amd/liblgcn.so ]; then
+    echo "liblgcn_stamps.so is missing or older than liblgcn.so: run 'make -C lanegcn-1_amd/csrc stamps' first" >&2
+    exit 1
+fi
 python bench.py > "$out/bench_s2.json" 2> "$out/bench_s2.err"
 echo "bench rc=$?"; tail -c 600 "$out/bench_s2.json" | head -c 300; echo
 python tools/stamps_lc.py 1 f16x2 32 2 2>&1 | grep -v amdgpu.ids > "$out/stamps_lc_tile_short.txt"
