@@ -727,7 +727,8 @@ def _net_replay_or_run(self, eng, hfb, feats, rot, orig, sizes):
     is uploaded and run eagerly.  Net.graph_cache = False disables it."""
     m = hfb.meta
     sig = (m["n_nodes"], m["n_actors"], tuple(m["n_edges"]), tuple(sizes), m["cap_a2m"], m["cap_a2a"], ops.get_mma(),
-           ops.att_impl(), ops.att_pairs_impl(), ops.laneconv_impl(), Att.strict, sum(p._version for p in ops.module_params(self)))
+           ops.att_impl(), ops.att_pairs_impl(), ops.laneconv_impl(), Att.strict, ActorNet.impl, PredNet.impl,
+           sum(p._version for p in ops.module_params(self)))
     st = self.__dict__.setdefault("_graph_state", {"last": None, "sig": None, "graph": None})
     if Net.graph_cache and st["graph"] is not None and st["sig"] == sig:
         g, gfb, gin, gout = st["graph"]
