@@ -287,6 +287,242 @@ __global__ __launch_bounds__(512) void k_conv_gn(const ConvParams p) {
     }
 }
 
+// ---------------------------------------------------------------- a whole Res1d block in one launch -----
+// layers.Res1d (reference layers.py:142-190):  out = relu( GN2(conv2( relu(GN1(conv1(x))) )) + r ),  conv1 k = 3 stride s,
+// conv2 k = 3 stride 1, r = x (cin == c, s == 1) or GN_d(conv_d(x)) with conv_d k = 1 stride s.  Same 80-row workgroups:
+// the intermediate never leaves the CU -- GN1's output goes straight into a second pair of operand planes (Y), the
+// shortcut's 1 x 1 convolution runs on the staged input right behind conv1 and its normalised rows wait in registers.
+struct Res1dParams {
+    const float *x;                    // [A, lin, cin]
+    int64_t n_act;
+    int lin, cin, c, stride, lout;
+    const uint4 *w1, *w2, *wd;         // packed images (wd: null = identity shortcut)
+    const float *g1, *b1, *g2, *b2, *gd, *bd;
+    float eps;
+    float *out;                        // [A, lout, c]
+};
+
+__global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float s_red[2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = kConvRows / p.lout;
+    const int64_t a0 = (int64_t)blockIdx.x * na;
+    const int kpad = conv_kpad(p.cin), ldk = kpad + 8;
+    const int n_in = na * p.lin;
+    const int ldy = p.c + 8, ldt = p.c + 4;
+    // region 1: the input planes, later the fp32 tile; region 2: the intermediate's planes (80 rows + a zero row)
+    const size_t r1_planes = (size_t)2 * (n_in + 1) * ldk * 2, r1_tile = (size_t)kConvRows * ldt * 4;
+    const size_t r1 = ((r1_planes > r1_tile ? r1_planes : r1_tile) + 15) & ~(size_t)15;
+    uint16_t *P0 = reinterpret_cast<uint16_t *>(smem), *P1 = P0 + (n_in + 1) * ldk;
+    float *T = reinterpret_cast<float *>(smem);
+    uint16_t *Y0 = reinterpret_cast<uint16_t *>(smem + r1), *Y1 = Y0 + (kConvRows + 1) * ldy;
+
+    const int ncb = p.c >> 4, nw = 8 / ncb;
+    const int cb = wave % ncb, rb0 = wave / ncb, kq = lane >> 4;
+    const bool down = p.wd != nullptr;
+
+    // ---- stage x as two fp16 planes; zero row of Y
+    {
+        const int c4n = kpad / 4, total = (n_in + 1) * c4n;
+        for (int i0 = tid; i0 < total; i0 += 4 * 512) {
+            float4 v[4];
+            int rr[4], cc[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * 512;
+                const int r = i / c4n, c = 4 * (i - r * c4n);
+                rr[u] = r; cc[u] = c;
+                v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int ar = r / p.lin;
+                const int64_t a = a0 + ar;
+                if (i < total && r < n_in && a < p.n_act) {
+                    const float *src = p.x + (a * p.lin + (r - ar * p.lin)) * p.cin + c;
+                    if (c + 3 < p.cin && (p.cin & 3) == 0) v[u] = *reinterpret_cast<const float4 *>(src);
+                    else {
+                        if (c < p.cin) v[u].x = src[0];
+                        if (c + 1 < p.cin) v[u].y = src[1];
+                        if (c + 2 < p.cin) v[u].z = src[2];
+                        if (c + 3 < p.cin) v[u].w = src[3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (i0 + u * 512 < total) {
+                    const uint32_t h0 = Fmt<1>::pack(v[u].x, v[u].y), h1 = Fmt<1>::pack(v[u].z, v[u].w);
+                    const f32x2 q0 = Fmt<1>::unpack(h0), q1 = Fmt<1>::unpack(h1);
+                    *reinterpret_cast<uint2 *>(P0 + rr[u] * ldk + cc[u]) = make_uint2(h0, h1);
+                    *reinterpret_cast<uint2 *>(P1 + rr[u] * ldk + cc[u]) =
+                        make_uint2(Fmt<1>::pack(v[u].x - q0.x, v[u].y - q0.y), Fmt<1>::pack(v[u].z - q1.x, v[u].w - q1.y));
+                }
+            }
+        }
+        for (int i = tid; i < ldy / 4; i += 512) {
+            *reinterpret_cast<uint2 *>(Y0 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(Y1 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
+        }
+    }
+    lds_barrier();
+
+    // one convolution as shifted GEMMs over staged planes: out^T = W x^T, weight fragments one K-step ahead
+    f32x4 acc[kConvSub];
+    auto conv = [&](const uint16_t *Q0, const uint16_t *Q1, int ld, int zero_row, int lin_, int stride_, int ks_, int nkc_,
+                    const uint4 *wp) {
+        const int pad_ = (ks_ - 1) >> 1;
+        int base[kConvSub], lpos[kConvSub];
+#pragma unroll
+        for (int i = 0; i < kConvSub; ++i) {
+            acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int r = 16 * (rb0 + i * nw) + (lane & 15);
+            const int a = r / p.lout, l = r - a * p.lout;
+            base[i] = a * lin_;
+            lpos[i] = l * stride_ - pad_;
+        }
+        auto wfrag = [&](int s_, uint4 &h, uint4 &l_) {
+            const int64_t wb = (((int64_t)s_ * ncb + cb) * 2) << 6;
+            h = wp[wb + lane];
+            l_ = wp[wb + 64 + lane];
+        };
+        const int nks = ks_ * nkc_;
+        uint4 nb0, nb1;
+        wfrag(0, nb0, nb1);
+        for (int t = 0; t < ks_; ++t) {
+            int roff[kConvSub];
+#pragma unroll
+            for (int i = 0; i < kConvSub; ++i) {
+                const int li = lpos[i] + t;
+                roff[i] = ((li >= 0 && li < lin_) ? base[i] + li : zero_row) * ld + 8 * kq;
+            }
+            for (int kc = 0; kc < nkc_; ++kc) {
+                const uint4 b0 = nb0, b1 = nb1;
+                const int sn = t * nkc_ + kc + 1;
+                wfrag(sn < nks ? sn : nks - 1, nb0, nb1);
+#pragma unroll
+                for (int i = 0; i < kConvSub; ++i) {
+                    if (rb0 + i * nw < kConvSub) {
+                        const int off = roff[i] + 32 * kc;
+                        const uint4 a_hi = *reinterpret_cast<const uint4 *>(Q0 + off);
+                        const uint4 a_lo = *reinterpret_cast<const uint4 *>(Q1 + off);
+                        f32x4 c = acc[i];
+                        c = Fmt<1>::mfma(b0, a_lo, c);
+                        c = Fmt<1>::mfma(b1, a_hi, c);
+                        c = Fmt<1>::mfma(b0, a_hi, c);
+                        acc[i] = c;
+                    }
+                }
+            }
+        }
+    };
+    auto acc_to_tile = [&](const f32x4 (&q)[kConvSub]) {
+#pragma unroll
+        for (int i = 0; i < kConvSub; ++i)
+            if (rb0 + i * nw < kConvSub)
+                *reinterpret_cast<f32x4 *>(T + (16 * (rb0 + i * nw) + (lane & 15)) * ldt + 16 * cb + 4 * (lane >> 4)) = q[i];
+    };
+    // GroupNorm of the tile per actor (512 / na threads each, <= 5 float4 per thread with the same channel quad)
+    const int tpa = 512 / na, al = tid / tpa, j = tid - al * tpa;
+    const int c4 = p.c >> 2, n4 = p.lout * c4;
+    const int64_t a = a0 + al;
+    const int c = 4 * (j % c4);
+    const float per = (float)(p.lout * p.c);
+    const int g0 = (al * tpa) >> 5, ng = tpa >> 5;
+    auto tile_gn = [&](float4 (&v)[5], const float *gamma, const float *beta) {     // contains two barriers
+        const float4 g = *reinterpret_cast<const float4 *>(gamma + c), bt = *reinterpret_cast<const float4 *>(beta + c);
+        const float *Ta = T + al * p.lout * ldt;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = j + k * tpa;
+            v[k] = i < n4 ? *reinterpret_cast<const float4 *>(Ta + (i / c4) * ldt + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+        if ((tid & 31) == 0) s_red[0][tid >> 5] = s;
+        lds_barrier();
+        float mean = 0.f;
+        for (int k = 0; k < ng; ++k) mean += s_red[0][g0 + k];
+        mean = mean / per;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (j + k * tpa < n4) {
+                const float d0 = v[k].x - mean, d1 = v[k].y - mean, d2 = v[k].z - mean, d3 = v[k].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+        if ((tid & 31) == 0) s_red[1][tid >> 5] = q;
+        lds_barrier();
+        float var = 0.f;
+        for (int k = 0; k < ng; ++k) var += s_red[1][g0 + k];
+        const float rstd = 1.0f / sqrtf(var / per + p.eps);
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            v[k] = make_float4((v[k].x - mean) * rstd * g.x + bt.x, (v[k].y - mean) * rstd * g.y + bt.y,
+                               (v[k].z - mean) * rstd * g.z + bt.z, (v[k].w - mean) * rstd * g.w + bt.w);
+    };
+
+    // ---- conv1 (and the shortcut's 1 x 1 convolution) on the staged input
+    conv(P0, P1, ldk, n_in, p.lin, p.stride, 3, kpad >> 5, p.w1);
+    f32x4 acc1[kConvSub];
+#pragma unroll
+    for (int i = 0; i < kConvSub; ++i) acc1[i] = acc[i];
+    if (down) conv(P0, P1, ldk, n_in, p.lin, p.stride, 1, kpad >> 5, p.wd);
+    lds_barrier();                                              // the input planes are done with
+    acc_to_tile(acc1);
+    lds_barrier();
+    float4 v[5], res[5];
+    tile_gn(v, p.g1, p.b1);
+    // relu(GN1(conv1 x)) -> Y planes (row = al * lout + l: the output row numbering)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const int i = j + k * tpa;
+        if (i < n4) {
+            const float4 y = make_float4(relu_nan(v[k].x), relu_nan(v[k].y), relu_nan(v[k].z), relu_nan(v[k].w));
+            const int row = al * p.lout + i / c4;
+            const uint32_t h0 = Fmt<1>::pack(y.x, y.y), h1 = Fmt<1>::pack(y.z, y.w);
+            const f32x2 q0 = Fmt<1>::unpack(h0), q1 = Fmt<1>::unpack(h1);
+            *reinterpret_cast<uint2 *>(Y0 + row * ldy + c) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2 *>(Y1 + row * ldy + c) =
+                make_uint2(Fmt<1>::pack(y.x - q0.x, y.y - q0.y), Fmt<1>::pack(y.z - q1.x, y.w - q1.y));
+        }
+    }
+    // ---- the shortcut
+    if (down) {
+        lds_barrier();                                          // every read of the conv1 tile is done
+        acc_to_tile(acc);
+        lds_barrier();
+        tile_gn(res, p.gd, p.bd);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = j + k * tpa;
+            res[k] = (a < p.n_act && i < n4) ? *reinterpret_cast<const float4 *>(p.x + (a * p.lout + i / c4) * p.c + c)
+                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    lds_barrier();                                              // Y complete; the tile is free again
+    // ---- conv2 on the intermediate, GN2, + shortcut, ReLU
+    conv(Y0, Y1, ldy, kConvRows, p.lout, 1, 3, p.c >> 5, p.w2);
+    acc_to_tile(acc);                                           // nobody reads T between the barrier above and this store
+    lds_barrier();
+    tile_gn(v, p.g2, p.b2);
+    if (a < p.n_act) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const int i = j + k * tpa;
+            if (i < n4) {
+                const float4 y = make_float4(relu_nan(v[k].x + res[k].x), relu_nan(v[k].y + res[k].y),
+                                             relu_nan(v[k].z + res[k].z), relu_nan(v[k].w + res[k].w));
+                *reinterpret_cast<float4 *>(p.out + (a * p.lout + i / c4) * p.c + c) = y;
+            }
+        }
+    }
+}
+
 }  // namespace lgcn
 
 using namespace lgcn;
@@ -346,6 +582,36 @@ int lgcn_conv1d_gn(const float *x, int64_t n_act, int lin, int cin, const void *
     }
     const unsigned grid = (unsigned)((n_act + na - 1) / na);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, (hipStream_t)stream, p);
+    return launch_status();
+}
+
+int lgcn_res1d_gn(const float *x, int64_t n_act, int lin, int cin, int c, int stride, const void *w1p, const float *g1,
+                  const float *b1, const void *w2p, const float *g2, const float *b2, const void *wdp, const float *gd,
+                  const float *bd, float eps, float *out, void *stream) {
+    if (n_act < 0) return LGCN_EINVAL;
+    const int lout = stride > 0 ? (lin + 2 - 3) / stride + 1 : 0;
+    if (!conv_shape_ok(cin, c, 3, stride, lin, lout) || (c & 31)) return LGCN_ESHAPE;
+    if (wdp == nullptr && (cin != c || stride != 1)) return LGCN_ESHAPE;      // identity shortcut: same shape in and out
+    if ((wdp == nullptr) != (gd == nullptr) || (wdp == nullptr) != (bd == nullptr)) return LGCN_EINVAL;
+    if (n_act == 0) return LGCN_OK;
+    if (n_act > 0x7fffffff / (kConvRows * 128)) return LGCN_ESHAPE;
+    const void *al[] = {x, w1p, g1, b1, w2p, g2, b2, out};
+    for (const void *v : al) { LGCN_CHECK_PTR(v); LGCN_CHECK_ALIGN16(v); }
+    if (wdp != nullptr) { LGCN_CHECK_ALIGN16(wdp); LGCN_CHECK_ALIGN16(gd); LGCN_CHECK_ALIGN16(bd); }
+    Res1dParams p;
+    p.x = x; p.n_act = n_act; p.lin = lin; p.cin = cin; p.c = c; p.stride = stride; p.lout = lout;
+    p.w1 = reinterpret_cast<const uint4 *>(w1p); p.w2 = reinterpret_cast<const uint4 *>(w2p); p.wd = reinterpret_cast<const uint4 *>(wdp);
+    p.g1 = g1; p.b1 = b1; p.g2 = g2; p.b2 = b2; p.gd = gd; p.bd = bd; p.eps = eps; p.out = out;
+    const int na = kConvRows / lout;
+    const size_t r1_planes = (size_t)2 * (na * lin + 1) * (conv_kpad(cin) + 8) * 2, r1_tile = (size_t)kConvRows * (c + 4) * 4;
+    const size_t r1 = ((r1_planes > r1_tile ? r1_planes : r1_tile) + 15) & ~(size_t)15;
+    const size_t lds = r1 + (size_t)2 * (kConvRows + 1) * (c + 8) * 2;
+    if (lds > 159 * 1024) return LGCN_ESHAPE;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_res1d_gn), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k_res1d_gn, dim3((unsigned)((n_act + na - 1) / na)), dim3(512), lds, (hipStream_t)stream, p);
     return launch_status();
 }
 

@@ -569,7 +569,18 @@ class ActorNet(nn.Module):
         def cg(conv: nn.Conv1d, norm: nn.GroupNorm, x: Tensor, **kw) -> Tensor:
             return ops.conv1d_gn(x, conv.weight, conv.stride[0], norm.weight, norm.bias, norm.eps, **kw)
 
+        cus = torch.cuda.get_device_properties(actors.device).multi_processor_count
+
         def res1d(b: Res1d, x: Tensor) -> Tensor:
+            # the one-launch block keeps the intermediate's planes beside the tile: at 128 channels that is 88 KB of LDS,
+            # one workgroup per CU -- a loss once there are more workgroups than CUs (the output block at L = 20:
+            # 52 us against 2 x 22.5)
+            lout = (x.shape[1] - 1) // b.conv1.stride[0] + 1
+            wgs = -(-x.shape[0] // max(80 // max(lout, 1), 1))
+            if (b.conv1.out_channels < 128 or wgs <= cus) and ActorNet.fuse_blocks and b.act and b.conv1.kernel_size[0] == 3 and b.conv2.kernel_size[0] == 3 and \
+                    b.conv2.stride[0] == 1 and b.bn1.eps == b.bn2.eps and \
+                    (b.downsample is None or (b.downsample[0].kernel_size[0] == 1 and b.downsample[1].eps == b.bn1.eps)):
+                return ops.res1d_gn(x, b)                                 # the whole block in one launch
             out = cg(b.conv1, b.bn1, x, relu=True)
             skip = x if b.downsample is None else cg(b.downsample[0], b.downsample[1], x)
             return cg(b.conv2, b.bn2, out, res=skip, relu=b.act)
@@ -600,8 +611,10 @@ class ActorNet(nn.Module):
         return ok and all(n in (5, 10, 20) for n in lens) and all(lens[i] == 2 * lens[i + 1] for i in range(len(lens) - 1)) and \
             all(c.in_channels <= 128 and c.out_channels in (32, 64, 128) and c.kernel_size[0] in (1, 3) and c.stride[0] in (1, 2) for c in convs)
 
-    # "hip": lgcn_conv1d_gn launches; "miopen": stock channels-last convolutions + lgcn_gn_cl (LGCN_ACTORNET)
+    # "hip": lgcn_conv1d_gn / lgcn_res1d_gn launches; "miopen": stock channels-last convolutions + lgcn_gn_cl (LGCN_ACTORNET)
     impl = os.environ.get("LGCN_ACTORNET", "hip")
+    # a Res1d block (conv + GN + ReLU + conv + GN + shortcut + ReLU) in ONE launch (lgcn_res1d_gn) instead of two or three
+    fuse_blocks = os.environ.get("LGCN_ACTORNET_BLOCKS", "1") != "0"
 
     def _channels_last_ok(self, actors: Tensor) -> bool:
         mods = [b for g in self.groups for b in g] + [self.output]

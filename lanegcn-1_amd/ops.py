@@ -410,6 +410,29 @@ def conv1d_gn(x: torch.Tensor, weight: torch.Tensor, stride: int, gamma, beta, e
     return out
 
 
+def res1d_gn(x: torch.Tensor, block) -> torch.Tensor:
+    """A whole layers.Res1d block (conv1 k3 + GN + ReLU + conv2 k3 + GN + shortcut [identity | conv k1 + GN] + ReLU) on a
+    channels-last tensor x [A, L, Cin] in one launch (lgcn_res1d_gn) -> [A, Lout, C]."""
+    lib = L.load()
+    x = _dev(x, torch.float32, "x")
+    A_, lin, cin = x.shape
+    c1, c2, ds = block.conv1, block.conv2, block.downsample
+    c, stride = c1.out_channels, c1.stride[0]
+    if c1.in_channels != cin or c2.in_channels != c or c2.out_channels != c:
+        raise L.LgcnError("res1d_gn: block does not match the input's channels")
+    lout = (lin + 2 - 3) // stride + 1
+    out = torch.empty((A_, lout, c), dtype=torch.float32, device=x.device)
+    f32 = lambda t, n: _dev(t.detach(), torch.float32, n)
+    wd = gd = bd = None
+    if ds is not None:
+        wd, gd, bd = conv_packed(ds[0].weight), f32(ds[1].weight, "gd"), f32(ds[1].bias, "bd")
+    L.check(lib.lgcn_res1d_gn(_ptr(x), A_, lin, cin, c, stride, _ptr(conv_packed(c1.weight)), _ptr(f32(block.bn1.weight, "g1")),
+                              _ptr(f32(block.bn1.bias, "b1")), _ptr(conv_packed(c2.weight)), _ptr(f32(block.bn2.weight, "g2")),
+                              _ptr(f32(block.bn2.bias, "b2")), _ptr(wd), _ptr(gd), _ptr(bd), float(block.bn1.eps), _ptr(out),
+                              _stream()), "lgcn_res1d_gn")
+    return out
+
+
 # ------------------------------------------------------------------ PredNet's tail (row f1)
 def pred_reg(h: Sequence[torch.Tensor], w: Sequence[torch.Tensor], b: Sequence[torch.Tensor], ctrs: torch.Tensor,
              wd: torch.Tensor, bd: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -743,6 +743,39 @@ def test_actor_net_hip_conv_path(hip):
         assert got.shape == (n, 128)
         assert float((got.cpu() - want).abs().max()) <= 1e-4, n
         assert float((got - other).abs().max()) <= 2e-4, n
+    # whole Res1d blocks in one launch (lgcn_res1d_gn) against the same module on the CPU, and the two HIP paths against each other
+    from lanegcn_amd.layers import Res1d
+    for cin, c, stride, lin in ((3, 32, 1, 20), (32, 32, 1, 20), (32, 64, 2, 20), (64, 64, 1, 10), (64, 128, 2, 10),
+                                (128, 128, 1, 5), (128, 128, 1, 20), (96, 128, 2, 20)):
+        torch.manual_seed(cin + c)
+        blk = Res1d(cin, c, stride=stride, norm="GN", ng=1).eval()
+        with torch.no_grad():
+            for q in blk.parameters():
+                if q.dim() == 1:
+                    q.uniform_(0.5, 1.5) if q.mean() > 0.5 else q.uniform_(-0.3, 0.3)
+        for A_ in (37, 1):
+            x = torch.randn(A_, cin, lin) * 2.0
+            with torch.no_grad():
+                want = blk(x)
+            blk = blk.cuda()
+            got = ops.res1d_gn(x.transpose(1, 2).contiguous().cuda(), blk)
+            blk = blk.cpu()
+            assert got.shape == (A_, want.shape[2], c)
+            err = float((got.cpu().transpose(1, 2) - want).abs().max())
+            assert err <= 1e-4, (cin, c, stride, lin, A_, err)
+    net = net.cuda()
+    x = (torch.randn(333, 3, 20) * 3.0).cuda()
+    prev = M.ActorNet.fuse_blocks
+    try:
+        with torch.no_grad():
+            M.ActorNet.fuse_blocks = True
+            y1 = net(x)
+            M.ActorNet.fuse_blocks = False
+            y0 = net(x)
+    finally:
+        M.ActorNet.fuse_blocks = prev
+    net = net.cpu()
+    assert float((y1 - y0).abs().max()) <= 1e-4
     # the op alone
     gen = torch.Generator().manual_seed(3)
     for cin, cout, ks, stride, lin, mode in ((3, 32, 3, 1, 20, 0), (3, 32, 1, 1, 20, 0), (32, 32, 3, 1, 20, 1), (32, 64, 3, 2, 20, 0),

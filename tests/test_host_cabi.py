@@ -196,6 +196,18 @@ def test_conv_entry_points_validate_before_launching(lib):
     assert call(x=264) == EALIGN and call(wp=8) == EALIGN
     assert call(n=1 << 40) == ESHAPE
 
+    def blk(x=256, n=8, lin=20, cin=32, c=32, stride=1, w1=256, g1=256, b1=256, w2=256, g2=256, b2=256, wd=None, gd=None, bd=None,
+            out=256):
+        return l.lgcn_res1d_gn(x, n, lin, cin, c, stride, w1, g1, b1, w2, g2, b2, wd, gd, bd, 1e-5, out, None)
+
+    assert blk(n=0) == 0 and blk(n=0, cin=64, c=128, stride=2, lin=10, wd=256, gd=256, bd=256) == 0
+    assert blk(n=-1) == EINVAL
+    assert blk(cin=64, c=32) == ESHAPE and blk(stride=2) == ESHAPE            # an identity shortcut needs the same shape
+    assert blk(wd=256) == EINVAL and blk(gd=256) == EINVAL                     # shortcut weights: all three or none
+    assert blk(c=48, cin=48) == ESHAPE and blk(lin=8) == ESHAPE and blk(stride=3, wd=256, gd=256, bd=256) == ESHAPE
+    assert blk(x=None) == EINVAL and blk(w2=None) == EINVAL and blk(out=260) == EALIGN
+    assert blk(cin=64, c=128, wd=260, gd=256, bd=256) == EALIGN
+
 
 def test_pred_tail_entry_points_validate_before_launching(lib):
     """lgcn_pred_reg / lgcn_pred_final (PredNet's tail): mode and horizon limits, pointers and alignment."""
