@@ -181,6 +181,13 @@ int lgcn_conv1d_gn(const float *x, int64_t n_act, int lin, int cin, const void *
 int lgcn_res1d_gn(const float *x, int64_t n_act, int lin, int cin, int c, int stride, const void *w1p, const float *g1,
                   const float *b1, const void *w2p, const float *g2, const float *b2, const void *wdp, const float *gd,
                   const float *bd, float eps, float *out, void *stream);
+/* Two Res1d blocks in one launch: the block above followed by a second one with the identity shortcut (c -> c, stride 1;
+ * w1q .. b2q: its conv1 / GN1 / conv2 / GN2) -- a group of ActorNet (lanegcn.py:228-241).  Only the second block's output
+ * is written. */
+int lgcn_res1d_pair_gn(const float *x, int64_t n_act, int lin, int cin, int c, int stride, const void *w1p, const float *g1,
+                       const float *b1, const void *w2p, const float *g2, const float *b2, const void *wdp, const float *gd,
+                       const float *bd, const void *w1q, const float *g1q, const float *b1q, const void *w2q, const float *g2q,
+                       const float *b2q, float eps, float *out, void *stream);
 
 /* ------------------------------------------------------------------ */
 /* PredNet's tail                         */

@@ -127,6 +127,7 @@ SIGNATURES = {
     "lgcn_conv_pack_weight": (C.c_int, [_P, _I, _I, _I, _P, _P]),
     "lgcn_conv1d_gn": (C.c_int, [_P, _L, _I, _I, _P, _I, _I, _I, _P, _P, _F, _P, _I, _I, _P, _P]),
     "lgcn_res1d_gn": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
+    "lgcn_res1d_pair_gn": (C.c_int, [_P, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P]),
     "lgcn_pred_reg": (C.c_int, [C.POINTER(PredReg), _P]),
     "lgcn_pred_final": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "lgcn_scan_ws_elems": (C.c_int64, [_L]),

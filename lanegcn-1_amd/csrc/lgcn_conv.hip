@@ -298,6 +298,8 @@ struct Res1dParams {
     int lin, cin, c, stride, lout;
     const uint4 *w1, *w2, *wd;         // packed images (wd: null = identity shortcut)
     const float *g1, *b1, *g2, *b2, *gd, *bd;
+    const uint4 *w1b, *w2b;            // a second block with the identity shortcut chained behind the first (null: none)
+    const float *g1b, *b1b, *g2b, *b2b;
     float eps;
     float *out;                        // [A, lout, c]
 };
@@ -317,6 +319,8 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
     uint16_t *P0 = reinterpret_cast<uint16_t *>(smem), *P1 = P0 + (n_in + 1) * ldk;
     float *T = reinterpret_cast<float *>(smem);
     uint16_t *Y0 = reinterpret_cast<uint16_t *>(smem + r1), *Y1 = Y0 + (kConvRows + 1) * ldy;
+    const bool chain = p.w1b != nullptr;                        // region 3 (chained block only): the first block's output planes
+    uint16_t *Z0 = Y1 + (kConvRows + 1) * ldy, *Z1 = Z0 + (kConvRows + 1) * ldy;
 
     const int ncb = p.c >> 4, nw = 8 / ncb;
     const int cb = wave % ncb, rb0 = wave / ncb, kq = lane >> 4;
@@ -361,6 +365,10 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
         for (int i = tid; i < ldy / 4; i += 512) {
             *reinterpret_cast<uint2 *>(Y0 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
             *reinterpret_cast<uint2 *>(Y1 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
+            if (chain) {
+                *reinterpret_cast<uint2 *>(Z0 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
+                *reinterpret_cast<uint2 *>(Z1 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
+            }
         }
     }
     lds_barrier();
@@ -476,20 +484,29 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
     lds_barrier();
     float4 v[5], res[5];
     tile_gn(v, p.g1, p.b1);
-    // relu(GN1(conv1 x)) -> Y planes (row = al * lout + l: the output row numbering)
+    // a thread's normalised values -> operand planes (row = al * lout + l: the output row numbering)
+    auto to_planes = [&](uint16_t *U0, uint16_t *U1, const float4 (&y_)[5]) {
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int i = j + k * tpa;
-        if (i < n4) {
-            const float4 y = make_float4(relu_nan(v[k].x), relu_nan(v[k].y), relu_nan(v[k].z), relu_nan(v[k].w));
-            const int row = al * p.lout + i / c4;
-            const uint32_t h0 = Fmt<1>::pack(y.x, y.y), h1 = Fmt<1>::pack(y.z, y.w);
-            const f32x2 q0 = Fmt<1>::unpack(h0), q1 = Fmt<1>::unpack(h1);
-            *reinterpret_cast<uint2 *>(Y0 + row * ldy + c) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2 *>(Y1 + row * ldy + c) =
-                make_uint2(Fmt<1>::pack(y.x - q0.x, y.y - q0.y), Fmt<1>::pack(y.z - q1.x, y.w - q1.y));
+        for (int k = 0; k < 5; ++k) {
+            const int i = j + k * tpa;
+            if (i < n4) {
+                const float4 y = y_[k];
+                const int row = al * p.lout + i / c4;
+                const uint32_t h0 = Fmt<1>::pack(y.x, y.y), h1 = Fmt<1>::pack(y.z, y.w);
+                const f32x2 q0 = Fmt<1>::unpack(h0), q1 = Fmt<1>::unpack(h1);
+                *reinterpret_cast<uint2 *>(U0 + row * ldy + c) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(U1 + row * ldy + c) =
+                    make_uint2(Fmt<1>::pack(y.x - q0.x, y.y - q0.y), Fmt<1>::pack(y.z - q1.x, y.w - q1.y));
+            }
         }
-    }
+    };
+    auto relu5 = [&](float4 (&y_)[5]) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            y_[k] = make_float4(relu_nan(y_[k].x), relu_nan(y_[k].y), relu_nan(y_[k].z), relu_nan(y_[k].w));
+    };
+    relu5(v);
+    to_planes(Y0, Y1, v);                                       // relu(GN1(conv1 x))
     // ---- the shortcut
     if (down) {
         lds_barrier();                                          // every read of the conv1 tile is done
@@ -510,17 +527,43 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
     acc_to_tile(acc);                                           // nobody reads T between the barrier above and this store
     lds_barrier();
     tile_gn(v, p.g2, p.b2);
-    if (a < p.n_act) {
+    auto add_res_relu = [&]() {
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const int i = j + k * tpa;
-            if (i < n4) {
-                const float4 y = make_float4(relu_nan(v[k].x + res[k].x), relu_nan(v[k].y + res[k].y),
-                                             relu_nan(v[k].z + res[k].z), relu_nan(v[k].w + res[k].w));
-                *reinterpret_cast<float4 *>(p.out + (a * p.lout + i / c4) * p.c + c) = y;
+            const bool live = j + k * tpa < n4;
+            v[k] = make_float4(live ? relu_nan(v[k].x + res[k].x) : 0.f, live ? relu_nan(v[k].y + res[k].y) : 0.f,
+                               live ? relu_nan(v[k].z + res[k].z) : 0.f, live ? relu_nan(v[k].w + res[k].w) : 0.f);
+        }
+    };
+    auto store_out = [&]() {
+        if (a < p.n_act) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int i = j + k * tpa;
+                if (i < n4) *reinterpret_cast<float4 *>(p.out + (a * p.lout + i / c4) * p.c + c) = v[k];
             }
         }
-    }
+    };
+    add_res_relu();
+    if (!chain) { store_out(); return; }
+    // ---- the chained block (identity shortcut = the values this thread holds): its input planes are region 3
+    to_planes(Z0, Z1, v);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) res[k] = v[k];
+    lds_barrier();                                              // Z complete
+    conv(Z0, Z1, ldy, kConvRows, p.lout, 1, 3, p.c >> 5, p.w1b);
+    acc_to_tile(acc);
+    lds_barrier();
+    tile_gn(v, p.g1b, p.b1b);
+    relu5(v);
+    to_planes(Y0, Y1, v);
+    lds_barrier();
+    conv(Y0, Y1, ldy, kConvRows, p.lout, 1, 3, p.c >> 5, p.w2b);
+    acc_to_tile(acc);
+    lds_barrier();
+    tile_gn(v, p.g2b, p.b2b);
+    add_res_relu();
+    store_out();
 }
 
 }  // namespace lgcn
@@ -585,9 +628,9 @@ int lgcn_conv1d_gn(const float *x, int64_t n_act, int lin, int cin, const void *
     return launch_status();
 }
 
-int lgcn_res1d_gn(const float *x, int64_t n_act, int lin, int cin, int c, int stride, const void *w1p, const float *g1,
-                  const float *b1, const void *w2p, const float *g2, const float *b2, const void *wdp, const float *gd,
-                  const float *bd, float eps, float *out, void *stream) {
+static int res1d_launch(const float *x, int64_t n_act, int lin, int cin, int c, int stride, const void *w1p, const float *g1,
+                        const float *b1, const void *w2p, const float *g2, const float *b2, const void *wdp, const float *gd,
+                        const float *bd, const void *const *second, float eps, float *out, void *stream) {
     if (n_act < 0) return LGCN_EINVAL;
     const int lout = stride > 0 ? (lin + 2 - 3) / stride + 1 : 0;
     if (!conv_shape_ok(cin, c, 3, stride, lin, lout) || (c & 31)) return LGCN_ESHAPE;
@@ -602,10 +645,17 @@ int lgcn_res1d_gn(const float *x, int64_t n_act, int lin, int cin, int c, int st
     p.x = x; p.n_act = n_act; p.lin = lin; p.cin = cin; p.c = c; p.stride = stride; p.lout = lout;
     p.w1 = reinterpret_cast<const uint4 *>(w1p); p.w2 = reinterpret_cast<const uint4 *>(w2p); p.wd = reinterpret_cast<const uint4 *>(wdp);
     p.g1 = g1; p.b1 = b1; p.g2 = g2; p.b2 = b2; p.gd = gd; p.bd = bd; p.eps = eps; p.out = out;
+    p.w1b = p.w2b = nullptr; p.g1b = p.b1b = p.g2b = p.b2b = nullptr;
+    if (second != nullptr) {          // {w1p, g1, b1, w2p, g2, b2} of the chained block
+        for (int i = 0; i < 6; ++i) { LGCN_CHECK_PTR(second[i]); LGCN_CHECK_ALIGN16(second[i]); }
+        p.w1b = reinterpret_cast<const uint4 *>(second[0]); p.g1b = reinterpret_cast<const float *>(second[1]);
+        p.b1b = reinterpret_cast<const float *>(second[2]); p.w2b = reinterpret_cast<const uint4 *>(second[3]);
+        p.g2b = reinterpret_cast<const float *>(second[4]); p.b2b = reinterpret_cast<const float *>(second[5]);
+    }
     const int na = kConvRows / lout;
     const size_t r1_planes = (size_t)2 * (na * lin + 1) * (conv_kpad(cin) + 8) * 2, r1_tile = (size_t)kConvRows * (c + 4) * 4;
     const size_t r1 = ((r1_planes > r1_tile ? r1_planes : r1_tile) + 15) & ~(size_t)15;
-    const size_t lds = r1 + (size_t)2 * (kConvRows + 1) * (c + 8) * 2;
+    const size_t lds = r1 + (size_t)(second != nullptr ? 4 : 2) * (kConvRows + 1) * (c + 8) * 2;
     if (lds > 159 * 1024) return LGCN_ESHAPE;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_res1d_gn), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
@@ -613,6 +663,20 @@ int lgcn_res1d_gn(const float *x, int64_t n_act, int lin, int cin, int c, int st
     }
     hipLaunchKernelGGL(k_res1d_gn, dim3((unsigned)((n_act + na - 1) / na)), dim3(512), lds, (hipStream_t)stream, p);
     return launch_status();
+}
+
+int lgcn_res1d_gn(const float *x, int64_t n_act, int lin, int cin, int c, int stride, const void *w1p, const float *g1,
+                  const float *b1, const void *w2p, const float *g2, const float *b2, const void *wdp, const float *gd,
+                  const float *bd, float eps, float *out, void *stream) {
+    return res1d_launch(x, n_act, lin, cin, c, stride, w1p, g1, b1, w2p, g2, b2, wdp, gd, bd, nullptr, eps, out, stream);
+}
+
+int lgcn_res1d_pair_gn(const float *x, int64_t n_act, int lin, int cin, int c, int stride, const void *w1p, const float *g1,
+                       const float *b1, const void *w2p, const float *g2, const float *b2, const void *wdp, const float *gd,
+                       const float *bd, const void *w1q, const float *g1q, const float *b1q, const void *w2q, const float *g2q,
+                       const float *b2q, float eps, float *out, void *stream) {
+    const void *second[6] = {w1q, g1q, b1q, w2q, g2q, b2q};
+    return res1d_launch(x, n_act, lin, cin, c, stride, w1p, g1, b1, w2p, g2, b2, wdp, gd, bd, second, eps, out, stream);
 }
 
 }  // extern "C"

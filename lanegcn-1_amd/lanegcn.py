@@ -571,15 +571,31 @@ class ActorNet(nn.Module):
 
         cus = torch.cuda.get_device_properties(actors.device).multi_processor_count
 
+        def fusable(b: Res1d) -> bool:
+            return ActorNet.fuse_blocks and b.act and b.conv1.kernel_size[0] == 3 and b.conv2.kernel_size[0] == 3 and \
+                b.conv2.stride[0] == 1 and b.bn1.eps == b.bn2.eps and \
+                (b.downsample is None or (b.downsample[0].kernel_size[0] == 1 and b.downsample[1].eps == b.bn1.eps))
+
+        def group(g, x: Tensor) -> Tensor:
+            # two blocks (the second with the identity shortcut) in one launch: three plane sets + tile, 134 KB of LDS at
+            # 128 channels -- only while the workgroups still fit the CUs once each
+            if len(g) == 2 and fusable(g[0]) and fusable(g[1]) and g[1].downsample is None and g[1].conv1.stride[0] == 1 and \
+                    g[1].bn1.eps == g[0].bn1.eps and ActorNet.fuse_groups:
+                lout = (x.shape[1] - 1) // g[0].conv1.stride[0] + 1
+                wgs = -(-x.shape[0] // max(80 // max(lout, 1), 1))
+                if g[0].conv1.out_channels < 128 or wgs <= cus:
+                    return ops.res1d_gn(x, g[0], second=g[1])
+            for b in g:
+                x = res1d(b, x)
+            return x
+
         def res1d(b: Res1d, x: Tensor) -> Tensor:
             # the one-launch block keeps the intermediate's planes beside the tile: at 128 channels that is 88 KB of LDS,
             # one workgroup per CU -- a loss once there are more workgroups than CUs (the output block at L = 20:
             # 52 us against 2 x 22.5)
             lout = (x.shape[1] - 1) // b.conv1.stride[0] + 1
             wgs = -(-x.shape[0] // max(80 // max(lout, 1), 1))
-            if (b.conv1.out_channels < 128 or wgs <= cus) and ActorNet.fuse_blocks and b.act and b.conv1.kernel_size[0] == 3 and b.conv2.kernel_size[0] == 3 and \
-                    b.conv2.stride[0] == 1 and b.bn1.eps == b.bn2.eps and \
-                    (b.downsample is None or (b.downsample[0].kernel_size[0] == 1 and b.downsample[1].eps == b.bn1.eps)):
+            if (b.conv1.out_channels < 128 or wgs <= cus) and fusable(b):
                 return ops.res1d_gn(x, b)                                 # the whole block in one launch
             out = cg(b.conv1, b.bn1, x, relu=True)
             skip = x if b.downsample is None else cg(b.downsample[0], b.downsample[1], x)
@@ -587,8 +603,7 @@ class ActorNet(nn.Module):
 
         out, pyramid = actors.transpose(1, 2).contiguous(), []          # [A, 3, 20] -> [A, 20, 3]
         for g in self.groups:
-            for b in g:
-                out = res1d(b, out)
+            out = group(g, out)
             pyramid.append(out)
         lat = self.lateral[-1]
         out = cg(lat.conv, lat.norm, pyramid[-1], relu=lat.act)
@@ -615,6 +630,8 @@ class ActorNet(nn.Module):
     impl = os.environ.get("LGCN_ACTORNET", "hip")
     # a Res1d block (conv + GN + ReLU + conv + GN + shortcut + ReLU) in ONE launch (lgcn_res1d_gn) instead of two or three
     fuse_blocks = os.environ.get("LGCN_ACTORNET_BLOCKS", "1") != "0"
+    # the two Res1d blocks of a group in ONE launch (lgcn_res1d_pair_gn)
+    fuse_groups = os.environ.get("LGCN_ACTORNET_GROUPS", "1") != "0"
 
     def _channels_last_ok(self, actors: Tensor) -> bool:
         mods = [b for g in self.groups for b in g] + [self.output]

@@ -410,9 +410,10 @@ def conv1d_gn(x: torch.Tensor, weight: torch.Tensor, stride: int, gamma, beta, e
     return out
 
 
-def res1d_gn(x: torch.Tensor, block) -> torch.Tensor:
+def res1d_gn(x: torch.Tensor, block, second=None) -> torch.Tensor:
     """A whole layers.Res1d block (conv1 k3 + GN + ReLU + conv2 k3 + GN + shortcut [identity | conv k1 + GN] + ReLU) on a
-    channels-last tensor x [A, L, Cin] in one launch (lgcn_res1d_gn) -> [A, Lout, C]."""
+    channels-last tensor x [A, L, Cin] in one launch (lgcn_res1d_gn) -> [A, Lout, C]; with `second` (a Res1d with the
+    identity shortcut, C -> C) the two blocks run in the same launch (lgcn_res1d_pair_gn)."""
     lib = L.load()
     x = _dev(x, torch.float32, "x")
     A_, lin, cin = x.shape
@@ -426,10 +427,19 @@ def res1d_gn(x: torch.Tensor, block) -> torch.Tensor:
     wd = gd = bd = None
     if ds is not None:
         wd, gd, bd = conv_packed(ds[0].weight), f32(ds[1].weight, "gd"), f32(ds[1].bias, "bd")
-    L.check(lib.lgcn_res1d_gn(_ptr(x), A_, lin, cin, c, stride, _ptr(conv_packed(c1.weight)), _ptr(f32(block.bn1.weight, "g1")),
-                              _ptr(f32(block.bn1.bias, "b1")), _ptr(conv_packed(c2.weight)), _ptr(f32(block.bn2.weight, "g2")),
-                              _ptr(f32(block.bn2.bias, "b2")), _ptr(wd), _ptr(gd), _ptr(bd), float(block.bn1.eps), _ptr(out),
-                              _stream()), "lgcn_res1d_gn")
+    first = (_ptr(x), A_, lin, cin, c, stride, _ptr(conv_packed(c1.weight)), _ptr(f32(block.bn1.weight, "g1")),
+             _ptr(f32(block.bn1.bias, "b1")), _ptr(conv_packed(c2.weight)), _ptr(f32(block.bn2.weight, "g2")),
+             _ptr(f32(block.bn2.bias, "b2")), _ptr(wd), _ptr(gd), _ptr(bd))
+    if second is None:
+        L.check(lib.lgcn_res1d_gn(*first, float(block.bn1.eps), _ptr(out), _stream()), "lgcn_res1d_gn")
+        return out
+    q1, q2 = second.conv1, second.conv2
+    if second.downsample is not None or q1.in_channels != c or q1.out_channels != c or q2.in_channels != c or q2.out_channels != c:
+        raise L.LgcnError("res1d_gn: the chained block must be C -> C with the identity shortcut")
+    L.check(lib.lgcn_res1d_pair_gn(*first, _ptr(conv_packed(q1.weight)), _ptr(f32(second.bn1.weight, "g1q")),
+                                   _ptr(f32(second.bn1.bias, "b1q")), _ptr(conv_packed(q2.weight)),
+                                   _ptr(f32(second.bn2.weight, "g2q")), _ptr(f32(second.bn2.bias, "b2q")),
+                                   float(block.bn1.eps), _ptr(out), _stream()), "lgcn_res1d_pair_gn")
     return out
 
 

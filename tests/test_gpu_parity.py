@@ -763,19 +763,38 @@ def test_actor_net_hip_conv_path(hip):
             assert got.shape == (A_, want.shape[2], c)
             err = float((got.cpu().transpose(1, 2) - want).abs().max())
             assert err <= 1e-4, (cin, c, stride, lin, A_, err)
+    # two blocks of a group in one launch (lgcn_res1d_pair_gn) against the CPU modules
+    for cin, c, stride, lin in ((3, 32, 1, 20), (32, 64, 2, 20), (64, 128, 2, 10), (64, 64, 1, 10)):
+        torch.manual_seed(7 * cin + c)
+        b0, b1 = Res1d(cin, c, stride=stride, norm="GN", ng=1).eval(), Res1d(c, c, norm="GN", ng=1).eval()
+        with torch.no_grad():
+            for q in list(b0.parameters()) + list(b1.parameters()):
+                if q.dim() == 1:
+                    q.uniform_(0.5, 1.5) if q.mean() > 0.5 else q.uniform_(-0.3, 0.3)
+        for A_ in (37, 1):
+            x = torch.randn(A_, cin, lin) * 2.0
+            with torch.no_grad():
+                want = b1(b0(x))
+            b0, b1 = b0.cuda(), b1.cuda()
+            got = ops.res1d_gn(x.transpose(1, 2).contiguous().cuda(), b0, second=b1)
+            b0, b1 = b0.cpu(), b1.cpu()
+            err = float((got.cpu().transpose(1, 2) - want).abs().max())
+            assert got.shape == (A_, want.shape[2], c) and err <= 1e-4, (cin, c, stride, lin, A_, err)
     net = net.cuda()
     x = (torch.randn(333, 3, 20) * 3.0).cuda()
-    prev = M.ActorNet.fuse_blocks
+    prev = M.ActorNet.fuse_blocks, M.ActorNet.fuse_groups
     try:
         with torch.no_grad():
-            M.ActorNet.fuse_blocks = True
+            M.ActorNet.fuse_blocks, M.ActorNet.fuse_groups = True, True
+            y2 = net(x)
+            M.ActorNet.fuse_blocks, M.ActorNet.fuse_groups = True, False
             y1 = net(x)
             M.ActorNet.fuse_blocks = False
             y0 = net(x)
     finally:
-        M.ActorNet.fuse_blocks = prev
+        M.ActorNet.fuse_blocks, M.ActorNet.fuse_groups = prev
     net = net.cpu()
-    assert float((y1 - y0).abs().max()) <= 1e-4
+    assert float((y1 - y0).abs().max()) <= 1e-4 and float((y2 - y0).abs().max()) <= 1e-4
     # the op alone
     gen = torch.Generator().manual_seed(3)
     for cin, cout, ks, stride, lin, mode in ((3, 32, 3, 1, 20, 0), (3, 32, 1, 1, 20, 0), (32, 32, 3, 1, 20, 1), (32, 64, 3, 2, 20, 0),
