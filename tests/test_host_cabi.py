@@ -208,6 +208,16 @@ def test_conv_entry_points_validate_before_launching(lib):
     assert blk(x=None) == EINVAL and blk(w2=None) == EINVAL and blk(out=260) == EALIGN
     assert blk(cin=64, c=128, wd=260, gd=256, bd=256) == EALIGN
 
+    def pair(n=8, q=(256,) * 6, **kw):
+        a = dict(x=256, lin=20, cin=32, c=32, stride=1, w1=256, g1=256, b1=256, w2=256, g2=256, b2=256, wd=None, gd=None, bd=None)
+        a.update(kw)
+        return l.lgcn_res1d_pair_gn(a["x"], n, a["lin"], a["cin"], a["c"], a["stride"], a["w1"], a["g1"], a["b1"], a["w2"], a["g2"],
+                                    a["b2"], a["wd"], a["gd"], a["bd"], *q, 1e-5, 256, None)
+
+    assert pair(n=0) == 0 and pair(n=-1) == EINVAL
+    assert pair(q=(256, 256, None, 256, 256, 256)) == EINVAL and pair(q=(260, 256, 256, 256, 256, 256)) == EALIGN
+    assert pair(cin=64, c=32) == ESHAPE and pair(lin=7) == ESHAPE
+
 
 def test_pred_tail_entry_points_validate_before_launching(lib):
     """lgcn_pred_reg / lgcn_pred_final (PredNet's tail): mode and horizon limits, pointers and alignment."""
