@@ -176,7 +176,8 @@ int lgcn_conv1d_gn(const float *x, int64_t n_act, int lin, int cin, const void *
  * A whole layers.Res1d block (reference layers.py:142-190) in one launch, same layouts and shape limits as
  * lgcn_conv1d_gn:  out = relu( GN2(conv2( relu(GN1(conv1 x)) )) + r ),  conv1: k = 3, stride 1 / 2, cin -> c; conv2: k = 3,
  * stride 1, c -> c; r = x (wdp == NULL: needs cin == c, stride 1) or GN_d(conv_d x) with conv_d: k = 1, same stride
- * (wdp, gd, bd given).  c in {32, 64, 128}; w1p / w2p / wdp: lgcn_conv_pack_weight images.  The intermediate stays in LDS.
+ * (wdp, gd, bd given).  c in {32, 64, 128}; w1p / w2p / wdp: lgcn_conv_pack_weight images.  The intermediate stays in LDS
+ * (one region of <= 46 KB serves as input planes, tiles and intermediate planes in turn).
  */
 int lgcn_res1d_gn(const float *x, int64_t n_act, int lin, int cin, int c, int stride, const void *w1p, const float *g1,
                   const float *b1, const void *w2p, const float *g2, const float *b2, const void *wdp, const float *gd,

@@ -290,8 +290,10 @@ __global__ __launch_bounds__(512) void k_conv_gn(const ConvParams p) {
 // ---------------------------------------------------------------- a whole Res1d block in one launch -----
 // layers.Res1d (reference layers.py:142-190):  out = relu( GN2(conv2( relu(GN1(conv1(x))) )) + r ),  conv1 k = 3 stride s,
 // conv2 k = 3 stride 1, r = x (cin == c, s == 1) or GN_d(conv_d(x)) with conv_d k = 1 stride s.  Same 80-row workgroups:
-// the intermediate never leaves the CU -- GN1's output goes straight into a second pair of operand planes (Y), the
-// shortcut's 1 x 1 convolution runs on the staged input right behind conv1 and its normalised rows wait in registers.
+// the intermediate never leaves the CU -- GN1's output goes straight back into LDS as operand planes (Y), the shortcut's
+// 1 x 1 convolution runs on the staged input right behind conv1 and its normalised rows wait in registers.  A second
+// block with the identity shortcut can be chained behind the first (an ActorNet group): its input is the first block's
+// output as planes, its shortcut the values each thread still holds.
 struct Res1dParams {
     const float *x;                    // [A, lin, cin]
     int64_t n_act;
@@ -313,20 +315,19 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
     const int kpad = conv_kpad(p.cin), ldk = kpad + 8;
     const int n_in = na * p.lin;
     const int ldy = p.c + 8, ldt = p.c + 4;
-    // region 1: the input planes, later the fp32 tile; region 2: the intermediate's planes (80 rows + a zero row)
-    const size_t r1_planes = (size_t)2 * (n_in + 1) * ldk * 2, r1_tile = (size_t)kConvRows * ldt * 4;
-    const size_t r1 = ((r1_planes > r1_tile ? r1_planes : r1_tile) + 15) & ~(size_t)15;
+    // ONE region of LDS serves in turn as the input planes, every fp32 tile and every set of intermediate planes (80 rows
+    // + a zero row): each is dead before the next is written -- a tile is consumed into registers by tile_gn (whose two
+    // barriers every thread has passed when it returns), planes are done with at the barrier behind their convolution.
     uint16_t *P0 = reinterpret_cast<uint16_t *>(smem), *P1 = P0 + (n_in + 1) * ldk;
     float *T = reinterpret_cast<float *>(smem);
-    uint16_t *Y0 = reinterpret_cast<uint16_t *>(smem + r1), *Y1 = Y0 + (kConvRows + 1) * ldy;
-    const bool chain = p.w1b != nullptr;                        // region 3 (chained block only): the first block's output planes
-    uint16_t *Z0 = Y1 + (kConvRows + 1) * ldy, *Z1 = Z0 + (kConvRows + 1) * ldy;
+    uint16_t *Y0 = reinterpret_cast<uint16_t *>(smem), *Y1 = Y0 + (kConvRows + 1) * ldy;
+    const bool chain = p.w1b != nullptr;
 
     const int ncb = p.c >> 4, nw = 8 / ncb;
     const int cb = wave % ncb, rb0 = wave / ncb, kq = lane >> 4;
     const bool down = p.wd != nullptr;
 
-    // ---- stage x as two fp16 planes; zero row of Y
+    // ---- stage x as two fp16 planes
     {
         const int c4n = kpad / 4, total = (n_in + 1) * c4n;
         for (int i0 = tid; i0 < total; i0 += 4 * 512) {
@@ -360,14 +361,6 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
                     *reinterpret_cast<uint2 *>(P1 + rr[u] * ldk + cc[u]) =
                         make_uint2(Fmt<1>::pack(v[u].x - q0.x, v[u].y - q0.y), Fmt<1>::pack(v[u].z - q1.x, v[u].w - q1.y));
                 }
-            }
-        }
-        for (int i = tid; i < ldy / 4; i += 512) {
-            *reinterpret_cast<uint2 *>(Y0 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
-            *reinterpret_cast<uint2 *>(Y1 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
-            if (chain) {
-                *reinterpret_cast<uint2 *>(Z0 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
-                *reinterpret_cast<uint2 *>(Z1 + kConvRows * ldy + 4 * i) = make_uint2(0u, 0u);
             }
         }
     }
@@ -486,6 +479,10 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
     tile_gn(v, p.g1, p.b1);
     // a thread's normalised values -> operand planes (row = al * lout + l: the output row numbering)
     auto to_planes = [&](uint16_t *U0, uint16_t *U1, const float4 (&y_)[5]) {
+        if (tid < ldy / 4) {                                    // the zero row the padding taps read
+            *reinterpret_cast<uint2 *>(U0 + kConvRows * ldy + 4 * tid) = make_uint2(0u, 0u);
+            *reinterpret_cast<uint2 *>(U1 + kConvRows * ldy + 4 * tid) = make_uint2(0u, 0u);
+        }
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
             const int i = j + k * tpa;
@@ -506,11 +503,9 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
             y_[k] = make_float4(relu_nan(y_[k].x), relu_nan(y_[k].y), relu_nan(y_[k].z), relu_nan(y_[k].w));
     };
     relu5(v);
-    to_planes(Y0, Y1, v);                                       // relu(GN1(conv1 x))
     // ---- the shortcut
     if (down) {
-        lds_barrier();                                          // every read of the conv1 tile is done
-        acc_to_tile(acc);
+        acc_to_tile(acc);                                       // the conv1 tile is in registers everywhere
         lds_barrier();
         tile_gn(res, p.gd, p.bd);
     } else {
@@ -521,10 +516,12 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
                                              : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
-    lds_barrier();                                              // Y complete; the tile is free again
+    to_planes(Y0, Y1, v);                                       // relu(GN1(conv1 x))
+    lds_barrier();
     // ---- conv2 on the intermediate, GN2, + shortcut, ReLU
     conv(Y0, Y1, ldy, kConvRows, p.lout, 1, 3, p.c >> 5, p.w2);
-    acc_to_tile(acc);                                           // nobody reads T between the barrier above and this store
+    lds_barrier();                                              // the planes are done with: the tile takes their place
+    acc_to_tile(acc);
     lds_barrier();
     tile_gn(v, p.g2, p.b2);
     auto add_res_relu = [&]() {
@@ -546,12 +543,13 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
     };
     add_res_relu();
     if (!chain) { store_out(); return; }
-    // ---- the chained block (identity shortcut = the values this thread holds): its input planes are region 3
-    to_planes(Z0, Z1, v);
+    // ---- the chained block (identity shortcut = the values this thread holds)
+    to_planes(Y0, Y1, v);
 #pragma unroll
     for (int k = 0; k < 5; ++k) res[k] = v[k];
-    lds_barrier();                                              // Z complete
-    conv(Z0, Z1, ldy, kConvRows, p.lout, 1, 3, p.c >> 5, p.w1b);
+    lds_barrier();
+    conv(Y0, Y1, ldy, kConvRows, p.lout, 1, 3, p.c >> 5, p.w1b);
+    lds_barrier();
     acc_to_tile(acc);
     lds_barrier();
     tile_gn(v, p.g1b, p.b1b);
@@ -559,6 +557,7 @@ __global__ __launch_bounds__(512) void k_res1d_gn(const Res1dParams p) {
     to_planes(Y0, Y1, v);
     lds_barrier();
     conv(Y0, Y1, ldy, kConvRows, p.lout, 1, 3, p.c >> 5, p.w2b);
+    lds_barrier();
     acc_to_tile(acc);
     lds_barrier();
     tile_gn(v, p.g2b, p.b2b);
@@ -653,9 +652,10 @@ static int res1d_launch(const float *x, int64_t n_act, int lin, int cin, int c, 
         p.g2b = reinterpret_cast<const float *>(second[4]); p.b2b = reinterpret_cast<const float *>(second[5]);
     }
     const int na = kConvRows / lout;
-    const size_t r1_planes = (size_t)2 * (na * lin + 1) * (conv_kpad(cin) + 8) * 2, r1_tile = (size_t)kConvRows * (c + 4) * 4;
-    const size_t r1 = ((r1_planes > r1_tile ? r1_planes : r1_tile) + 15) & ~(size_t)15;
-    const size_t lds = r1 + (size_t)(second != nullptr ? 4 : 2) * (kConvRows + 1) * (c + 8) * 2;
+    const size_t in_planes = (size_t)2 * (na * lin + 1) * (conv_kpad(cin) + 8) * 2, tile = (size_t)kConvRows * (c + 4) * 4;
+    const size_t mid_planes = (size_t)2 * (kConvRows + 1) * (c + 8) * 2;
+    size_t lds = in_planes > tile ? in_planes : tile;          // one region, reused (see the kernel)
+    lds = lds > mid_planes ? lds : mid_planes;
     if (lds > 159 * 1024) return LGCN_ESHAPE;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_res1d_gn), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);

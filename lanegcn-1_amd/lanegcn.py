@@ -569,33 +569,22 @@ class ActorNet(nn.Module):
         def cg(conv: nn.Conv1d, norm: nn.GroupNorm, x: Tensor, **kw) -> Tensor:
             return ops.conv1d_gn(x, conv.weight, conv.stride[0], norm.weight, norm.bias, norm.eps, **kw)
 
-        cus = torch.cuda.get_device_properties(actors.device).multi_processor_count
-
         def fusable(b: Res1d) -> bool:
             return ActorNet.fuse_blocks and b.act and b.conv1.kernel_size[0] == 3 and b.conv2.kernel_size[0] == 3 and \
                 b.conv2.stride[0] == 1 and b.bn1.eps == b.bn2.eps and \
                 (b.downsample is None or (b.downsample[0].kernel_size[0] == 1 and b.downsample[1].eps == b.bn1.eps))
 
         def group(g, x: Tensor) -> Tensor:
-            # two blocks (the second with the identity shortcut) in one launch: three plane sets + tile, 134 KB of LDS at
-            # 128 channels -- only while the workgroups still fit the CUs once each
+            # two blocks (the second with the identity shortcut) in one launch
             if len(g) == 2 and fusable(g[0]) and fusable(g[1]) and g[1].downsample is None and g[1].conv1.stride[0] == 1 and \
                     g[1].bn1.eps == g[0].bn1.eps and ActorNet.fuse_groups:
-                lout = (x.shape[1] - 1) // g[0].conv1.stride[0] + 1
-                wgs = -(-x.shape[0] // max(80 // max(lout, 1), 1))
-                if g[0].conv1.out_channels < 128 or wgs <= cus:
-                    return ops.res1d_gn(x, g[0], second=g[1])
+                return ops.res1d_gn(x, g[0], second=g[1])
             for b in g:
                 x = res1d(b, x)
             return x
 
         def res1d(b: Res1d, x: Tensor) -> Tensor:
-            # the one-launch block keeps the intermediate's planes beside the tile: at 128 channels that is 88 KB of LDS,
-            # one workgroup per CU -- a loss once there are more workgroups than CUs (the output block at L = 20:
-            # 52 us against 2 x 22.5)
-            lout = (x.shape[1] - 1) // b.conv1.stride[0] + 1
-            wgs = -(-x.shape[0] // max(80 // max(lout, 1), 1))
-            if (b.conv1.out_channels < 128 or wgs <= cus) and fusable(b):
+            if fusable(b):
                 return ops.res1d_gn(x, b)                                 # the whole block in one launch
             out = cg(b.conv1, b.bn1, x, relu=True)
             skip = x if b.downsample is None else cg(b.downsample[0], b.downsample[1], x)
