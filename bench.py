@@ -334,6 +334,30 @@ def extra_timings(mods, scenes, dev):
                 torch.cuda.synchronize()
                 ts.append(time.perf_counter() - t0)
         out["net_forward_dropin_ms"] = float(np.median(ts)) * 1e3
+        # the whole Net (ActorNet + hot path + PredNet + world-frame transform) from device-resident flat inputs, captured
+        # in one hipGraph: one forward at a time, and four captured forwards in flight on four streams
+        from lanegcn_amd.engine import FullNetEngine, collate_flat
+        eng = FullNetEngine(net)
+        lanes = []
+        for j in range(4):
+            sc = scenes                      # same batch, its own device buffers per lane
+            fbj = collate_flat(sc)
+            feats, rot, orig = eng.actor_inputs(sc)
+            g, _ = eng.capture(fbj, feats, rot, orig, [len(x["ctrs"]) for x in sc])
+            lanes.append((torch.cuda.Stream(), g, len(sc)))
+        for key, nl in (("net_forward_graph_ms", 1), ("net_forward_graph4_ms", 4)):
+            def run(n):
+                for i in range(n):
+                    st, g, _ = lanes[i % nl]
+                    with torch.cuda.stream(st):
+                        g.replay()
+                torch.cuda.synchronize()
+            run(8)
+            t0 = time.perf_counter()
+            run(40)
+            out[key] = (time.perf_counter() - t0) / 40 * 1e3
+        out["net_forward_graph4_scenes_per_s"] = float(np.mean([l[2] for l in lanes])) / out["net_forward_graph4_ms"] * 1e3
+        del lanes, eng
         net.train()
         loss_fn = M.Loss(M.config).to(dev)
         from lanegcn_amd.utils import Optimizer
