@@ -277,7 +277,7 @@ def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup):
         return res, eng_one
     # the lane streams are created FIRST: torch hands out its pool streams in order and ROCm maps consecutive HIP
     # streams to consecutive hardware queues (4 by default), so these S streams get S distinct queues
-    lane_streams = [torch.cuda.Stream() for _ in range(S)]
+    lane_streams = lanes_streams(S)
     lanes = []
     for j in range(S):
         sc = scenes if j == 0 else gen.synth_batch(args.workload, seed=100 + rank + 1000 * j, n_scenes=args.scenes)
@@ -307,6 +307,19 @@ def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup):
     assert "nonfinite" not in o1 or int(o1["nonfinite"].item()) == 0
     res["single_ms_per_step"] = single / steps * 1e3
     return res, eng_one
+
+
+_LANE_STREAMS = []
+
+
+def lanes_streams(n):
+    """The streams of the forwards in flight, created once per process: torch hands out streams round-robin over a few
+    hardware queues, so streams made later (other modes, the whole-Net figures) can land on the same queue twice; every
+    measurement with forwards in flight uses these."""
+    import torch
+    while len(_LANE_STREAMS) < n:
+        _LANE_STREAMS.append(torch.cuda.Stream())
+    return _LANE_STREAMS[:n]
 
 
 def extra_timings(mods, scenes, dev):
@@ -344,7 +357,7 @@ def extra_timings(mods, scenes, dev):
             fbj = collate_flat(sc)
             feats, rot, orig = eng.actor_inputs(sc)
             g, _ = eng.capture(fbj, feats, rot, orig, [len(x["ctrs"]) for x in sc])
-            lanes.append((torch.cuda.Stream(), g, len(sc)))
+            lanes.append((lanes_streams(4)[j], g, len(sc)))
         for key, nl in (("net_forward_graph_ms", 1), ("net_forward_graph4_ms", 4)):
             def run(n):
                 for i in range(n):
