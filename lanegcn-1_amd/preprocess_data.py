@@ -7,8 +7,9 @@ consumes, behind the reference's function names.
   dilated_nbrs(nbr, num_nodes, num_scales)          reference data.py:520-534: A^(2^i) by repeated boolean squaring
       (lgcn_bool_square*), device tensors in and out.
 
-Both need CUDA tensors (no CPU fallback).  `cross_angle` (the reference's optional sector test, which reads a module
-global `config`) is not built: passing it raises.
+Both need CUDA tensors (no CPU fallback).  `cross_angle`: the reference's optional sector test reads a module global
+`config` (preprocess_data.py:310-312) that the module never defines -- `config` is a local of its main() (:44) -- so
+passing it raises NameError there; it raises the same here, and the reference's own call (:250) never passes it.
 """
 from typing import Dict
 
@@ -30,8 +31,8 @@ def preprocess(graph: Dict, cross_dist: float, cross_angle=None) -> Dict:
     """Same inputs and outputs as the reference: graph holds ctrs, feats [N,2], lane_idcs [N], pre_pairs, suc_pairs,
     left_pairs, right_pairs [k,2] (LongTensors on the GPU, as after to_long(gpu(.))) and idx; returns
     {"left": {"u", "v"}, "right": {"u", "v"}, "idx"} with int16 numpy index arrays."""
-    if cross_angle is not None:
-        raise L.LgcnError("preprocess: the cross_angle sector test is not built on the HIP path")
+    if cross_angle is not None:        # as the reference: its branch dies on an undefined global (see the module docstring)
+        raise NameError("name 'config' is not defined")
     lane_idcs = graph["lane_idcs"]
     if not (torch.is_tensor(lane_idcs) and lane_idcs.is_cuda):
         raise L.LgcnError("preprocess: the HIP path needs CUDA tensors (no CPU fallback)")
