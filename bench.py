@@ -238,7 +238,10 @@ def roofline_of(layer_us, n_nodes, sum_e, mma, workload, impl, launches):
     }
 
 
-def time_steps(step, steps, warmup, barrier, dev):
+def time_steps(step, steps, warmup, barrier, dev, marks=None):
+    """W untimed steps, then exactly K steps between barrier + synchronize on both sides; max over ranks.
+    marks: a list that receives, per timed step, the host time at which the step was issued (seconds from t0) and
+    whatever step() returned (run_mode's step returns an event recorded behind the replay on its stream)."""
     from lanegcn_amd import dist as D
     for _ in range(warmup):
         step()
@@ -247,13 +250,43 @@ def time_steps(step, steps, warmup, barrier, dev):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
+        r = step()
+        if marks is not None:
+            marks.append((time.perf_counter() - t0, r))
     torch.cuda.synchronize()
     barrier()
     return D.max_over_ranks(time.perf_counter() - t0, dev)     # slowest rank
 
 
-def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup):
+def replay_trace(lanes, steps):
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(lanes[0][0]):
+        ev0.record()
+    evs = []
+    t0 = time.perf_counter()
+    issued = []
+    for k in range(steps):
+        st, gj = lanes[k % len(lanes)][:2]
+        with torch.cuda.stream(st):
+            gj.replay()
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+        evs.append(e)
+        issued.append((time.perf_counter() - t0) * 1e3)
+    torch.cuda.synchronize()
+    done = [ev0.elapsed_time(e) for e in evs]
+    S = len(lanes)
+    per_lane = [[done[k] - (done[k - S] if k >= S else 0.0) for k in range(j, steps, S)] for j in range(S)]
+    return {"steps": steps, "lanes": S, "step_done_ms": [round(x, 4) for x in done],
+            "step_issued_host_ms": [round(x, 4) for x in issued],
+            "forward_ms_by_lane": [[round(x, 4) for x in l] for l in per_lane],
+            "note": "step_done_ms[k]: device time at which step k's forward finished, from an event recorded on the idle "
+                    "GPU just before step 0 was issued; forward_ms_by_lane[j][i]: time between consecutive completions "
+                    "on lane j (its i-th forward)"}
+
+
+def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup, trace=False):
     """One arithmetic mode: S forwards in flight (the headline figure) and one forward at a time, both captured in
     hipGraphs.  In the 16-bit-plane modes both run LaneConv on the weight-stationary kernel ("tiled"; at S2 its
     "short" shape: 48-row blocks, one launch per layer); f32 and bf16x3 run the one-launch row-tile kernel
@@ -285,6 +318,13 @@ def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup):
         aj = actors if j == 0 else torch.randn(fbj.n_actors, C, device=dev).relu()
         gj, oj = eng_multi.capture(fbj, aj, mapnet_only=args.mapnet_only)
         lanes.append((lane_streams[j], gj, oj, fbj, aj))
+    # one-time costs of a graph belong to its capture, not to the first timed replays: every lane's graph is replayed a
+    # few times on the stream it will run on (executable-graph upload, first-touch of its private pool)
+    for st, gj in [l[:2] for l in lanes]:
+        with torch.cuda.stream(st):
+            for _ in range(3):
+                gj.replay()
+    torch.cuda.synchronize()
     counter = [0]
 
     def step():
@@ -297,6 +337,14 @@ def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup):
 
     elapsed = time_steps(step, steps, warmup, D.barrier, dev)
     res.update(ms_per_step=elapsed / steps * 1e3, elapsed=elapsed, streams=S)
+    if trace:
+        # the same K steps once more, untimed on the host, with a HIP event behind every replay: when each step finished
+        # on the device, measured from an event recorded on the idle GPU (attributes the fill / drain of the S lanes)
+        res["replay_trace"] = replay_trace(lanes, steps)
+        # steady state: the same step over >= 200 steps (the fixed costs of a timed region -- the first kernels of S
+        # forwards starting together on an idle chip, the last forwards finishing alone -- weigh 1 / steps)
+        n_st = max(200, steps)
+        res["steady_ms_per_step"] = time_steps(step, n_st, 0, D.barrier, dev) / n_st * 1e3
     # the range guard's device flag is part of every captured forward: none of them may have tripped
     assert not any(int(l[2]["nonfinite"].item()) for l in lanes if "nonfinite" in l[2]), "non-finite features in mode %s" % mma
     if impl_one == impl_multi:
@@ -334,7 +382,7 @@ def extra_timings(mods, scenes, dev):
         net = M.Net(M.config).to(dev)
         for name in ("map_net", "a2m", "m2m", "m2a", "a2a"):
             getattr(net, name).load_state_dict(mods[name].state_dict())
-        batch = gen.collate_fn([gen.from_numpy(s) for s in scenes])
+        batch = gen.collate_fn([gen.from_numpy(s) for s in scenes], pack=True)     # packed in the loader
         net.eval()
         with torch.no_grad():
             for _ in range(3):
@@ -442,7 +490,7 @@ def main():
     actors = actors_cpu.to(dev)
     log("rank %d: batch ready (N=%d nodes, A=%d actors, sumE=%d)" % (rank, fb.n_nodes, fb.n_actors, sum(fb.n_edges)))
 
-    head, eng = run_mode(args, mma, mods, scenes, fb, actors, dev, rank, args.steps, args.warmup)
+    head, eng = run_mode(args, mma, mods, scenes, fb, actors, dev, rank, args.steps, args.warmup, trace=(world == 1))
     elapsed = head["elapsed"]
     log("rank %d: %d steps in %.4f s (%s)" % (rank, args.steps, elapsed, mma))
 
@@ -523,6 +571,13 @@ def main():
         }
         if stages_tab is not None:
             line["stages"] = stages_tab
+        if "steady_ms_per_step" in head:
+            line["value_steady"] = args.gpus * n_scenes / (head["steady_ms_per_step"] * 1e-3)
+            line["steady_ms_per_step"] = head["steady_ms_per_step"]
+            line["value_note"] = ("value: exactly --steps steps between two synchronisations (the driver's K); value_steady: the "
+                                  "same step over max(200, K) steps, no warm-up in between.  A timed region starts on an idle "
+                                  "chip and ends when the last forward has drained: those fixed costs weigh 1 / K (replay_trace)")
+            line["replay_trace"] = head["replay_trace"]
         if "single_ms_per_step" in head:
             line["single_stream"] = {"value": args.gpus * n_scenes / (head["single_ms_per_step"] * 1e-3), "unit": "scenes/s",
                                      "ms_per_step": head["single_ms_per_step"], "laneconv_impl": head["laneconv_impl"]["single"]}

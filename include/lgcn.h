@@ -365,6 +365,17 @@ typedef struct {
     float *out_pre;          /* optional [N,128]: stage-1 sums T (pre-GN1)  (saved for backward) */
     float *out_mid;          /* optional [N,128]: Y = act(GN1(T)), the stage-2 operand          */
     float *out_pre2;         /* optional [N,128]: Z = Y W2^T (pre-GN2)                          */
+    /* Optional CHAINED outputs, computed from the block's final rows y (= out) before they leave the CU -- what the
+     * NEXT Att layer needs from these rows (reference lanegcn.py:696-699, after hoisting the row-wise Linears out of
+     * the pair loop: see lgcn_att_pairs):
+     *   ch_u_out = ReLU(GN_q(y W_q^T)) W_u^T    that layer's query + its ctx.0[:, 128:256] part (y are its targets)
+     *   ch_v_out = y W_v^T                      that layer's ctx.0[:, 256:384] part (y are its context rows: A2A)
+     * ch_wu != NULL selects the first (needs ch_wq, ch_gq_g, ch_gq_b, ch_u_out), ch_wv != NULL the second (needs
+     * ch_v_out).  Same arithmetic as separate lgcn_agg_mlp launches on `out`; saves their launches. */
+    const float *ch_wq, *ch_gq_g, *ch_gq_b, *ch_wu;
+    float *ch_u_out;
+    const float *ch_wv;
+    float *ch_v_out;
 } lgcn_agg_mlp_t;
 
 /*
@@ -436,6 +447,12 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *p_host, void *stream);
 /* Two independent row blocks (e.g. Att's per-target U and per-context V, lanegcn.py:696-699) in ONE launch when both
  * are split-precision problems without CSR relations; otherwise the same as two lgcn_agg_mlp calls. */
 int lgcn_agg_mlp_pair(const lgcn_agg_mlp_t *a_host, const lgcn_agg_mlp_t *b_host, void *stream);
+
+/* Up to LGCN_MAX_MULTI independent row blocks in ONE launch (the head of a fusion block: A2M.meta chained into the
+ * first Att's U, and the V rows of both of its Att layers, lanegcn.py:387-406), under the conditions of
+ * lgcn_agg_mlp_pair; otherwise the same as n lgcn_agg_mlp calls in order. */
+#define LGCN_MAX_MULTI 4
+int lgcn_agg_mlp_multi(const lgcn_agg_mlp_t *const *ps_host, int n, void *stream);
 
 /*
  * MapNet input stage, lanegcn.py:324-327:

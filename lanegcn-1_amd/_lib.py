@@ -61,6 +61,8 @@ class AggMlp(C.Structure):
         ("wp2", C.c_void_p), ("gn2_g", C.c_void_p), ("gn2_b", C.c_void_p),
         ("res", C.c_void_p), ("out", C.c_void_p), ("out_pre", C.c_void_p),
         ("out_mid", C.c_void_p), ("out_pre2", C.c_void_p),
+        ("ch_wq", C.c_void_p), ("ch_gq_g", C.c_void_p), ("ch_gq_b", C.c_void_p), ("ch_wu", C.c_void_p),
+        ("ch_u_out", C.c_void_p), ("ch_wv", C.c_void_p), ("ch_v_out", C.c_void_p),
     ]
 
 
@@ -111,6 +113,7 @@ SIGNATURES = {
     "lgcn_lc_plan_build": (C.c_int, [_P, _P, _L, _I, _I, _I, _I, C.POINTER(C.c_int32), _P, _P]),
     "lgcn_laneconv_fwd": (C.c_int, [C.POINTER(LaneConv), _P]),
     "lgcn_agg_mlp_pair": (C.c_int, [C.POINTER(AggMlp), C.POINTER(AggMlp), _P]),
+    "lgcn_agg_mlp_multi": (C.c_int, [C.POINTER(C.POINTER(AggMlp)), _I, _P]),
     "lgcn_gn_bwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _P, _P, _P, _P, _P, _P]),
     "lgcn_gn_fwd": (C.c_int, [_P, _P, _P, _P, _L, _F, _I, _P, _P]),
     "lgcn_gn_cl": (C.c_int, [_P, _L, _I, _I, _P, _P, _F, _P, _I, _I, _I, _P, _P]),

@@ -206,8 +206,15 @@ __device__ unsigned long long *g_att_stamps = nullptr;     // diagnostic build o
 //   in pair order and the sum is written at the row of the piece's FIRST pair; the other rows are not written.
 //   The tail then adds, per target with pairs [a, b), the rows {a} U {16 j : a < 16 j < b} (relation mode
 //   LGCN_REL_RANGE16 of lgcn_agg_mlp): 12 x fewer rows through HBM and through the tail's CUs for A2A at S2.
+#ifndef LGCN_WS_WAVES      // diagnostic builds only (make relucnd_nolimit / spill): another register budget for this kernel
+#define LGCN_WS_WAVES 4
+#endif
 template <int F>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(F == 0 ? 2 : 4)))
+#ifdef LGCN_WS_NUMVGPR
+__global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(LGCN_WS_NUMVGPR)))
+#else
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(F == 0 ? 2 : LGCN_WS_WAVES)))
+#endif
 void k_att_pairs_ws(const PairParams p, const int seg) {
     constexpr int RB = 4, ROWS = 64, NP = Fmt<F>::NP;
 #ifdef LGCN_STAMPS

@@ -21,7 +21,11 @@ using f32x16 = float __attribute__((ext_vector_type(16)));
 // an overflow of the 16-bit operand planes (inf - inf) or a NaN in the input must reach the output, where the
 // caller can see it, instead of being clamped to a plausible-looking zero on the way.  gfx950 has the IEEE 754-2019
 // maximum as one instruction (v_maximum3_f32).
+#ifdef LGCN_RELU_CND      // diagnostic build only (make relucnd, tools/relu_variant_check.py): the compare + select form
+__device__ __forceinline__ float relu_nan(float x) { return x < 0.f ? 0.f : x; }
+#else
 __device__ __forceinline__ float relu_nan(float x) { return __builtin_elementwise_maximum(x, 0.f); }
+#endif
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a release/acquire fence over ALL address spaces:
 // hipcc puts s_waitcnt vmcnt(0) in front of the s_barrier, i.e. every global load still in flight (prefetched weight

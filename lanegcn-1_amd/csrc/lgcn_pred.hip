@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_pred_reg(const PredRegParams p) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float2 w = *reinterpret_cast<const float2 *>(p.wd + 2 * (c + q));
-            o[q] = fmaxf(fmaf(dy, w.y, dx * w.x) + p.bd[c + q], 0.f);
+            o[q] = relu_nan(fmaf(dy, w.y, dx * w.x) + p.bd[c + q]);      // ATen's relu keeps a NaN
         }
         *reinterpret_cast<float4 *>(p.hd + ((int64_t)ar * p.n_mod + m) * 128 + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
@@ -116,7 +116,8 @@ __global__ __launch_bounds__(256) void k_pred_final(const PredFinalParams p) {
             c[m] = s + bc;
         }
     }
-    // descending order, equal scores in mode order; every lane holds all the scores
+    // descending order, equal scores in mode order, NaN scores first (torch.sort treats NaN as the largest value): a
+    // total order, so every rank 0 .. n_mod - 1 is taken exactly once and every slot of cls / out is written
     int order[kPredMaxMod];
 #pragma unroll
     for (int m = 0; m < kPredMaxMod; ++m) order[m] = 0;
@@ -126,7 +127,11 @@ __global__ __launch_bounds__(256) void k_pred_final(const PredFinalParams p) {
             int rank = 0;
 #pragma unroll
             for (int j = 0; j < kPredMaxMod; ++j)
-                if (j < p.n_mod && (c[j] > c[m] || (c[j] == c[m] && j < m))) ++rank;
+                if (j < p.n_mod) {
+                    const bool nj = c[j] != c[j], nm = c[m] != c[m];
+                    const bool before = (nj || nm) ? (nj && (!nm || j < m)) : (c[j] > c[m] || (c[j] == c[m] && j < m));
+                    if (before) ++rank;
+                }
 #pragma unroll
             for (int r = 0; r < kPredMaxMod; ++r)
                 if (r == rank) order[r] = m;

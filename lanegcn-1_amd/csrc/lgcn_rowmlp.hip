@@ -507,6 +507,9 @@ int lgcn_pack_weight_batch(const lgcn_pack_job_t *jobs, int n_jobs, int mma, voi
     return launch_status();
 }
 
+static_assert(sizeof(lgcn_agg_mlp_t) == 32 + LGCN_MAX_REL * 24 + 23 * 8 && LGCN_MAX_REL == 16,
+              "lgcn_agg_mlp_t layout: keep lanegcn-1_amd/_lib.py (AggMlp) and tests/test_host_cabi.py in step");
+
 static int validate_agg(const lgcn_agg_mlp_t &p, bool *need_col_out) {
     if (p.n_rows < 0 || p.n_rel < 1 || p.n_rel > LGCN_MAX_REL || !valid_mma(p.mma)) return LGCN_EINVAL;
     constexpr int kKnownFlags = LGCN_F_GN1 | LGCN_F_RELU1 | LGCN_F_GEMM2 | LGCN_F_GN2 | LGCN_F_RES | LGCN_F_RELU2;
@@ -552,7 +555,32 @@ static int validate_agg(const lgcn_agg_mlp_t &p, bool *need_col_out) {
     if (p.out_pre) LGCN_CHECK_ALIGN16(p.out_pre);
     if (p.out_mid) LGCN_CHECK_ALIGN16(p.out_mid);
     if (p.out_pre2) LGCN_CHECK_ALIGN16(p.out_pre2);
+    if (p.ch_wu) {
+        const void *q[] = {p.ch_wq, p.ch_gq_g, p.ch_gq_b, p.ch_wu, p.ch_u_out};
+        for (const void *v : q) { LGCN_CHECK_PTR(v); LGCN_CHECK_ALIGN16(v); }
+    }
+    if (p.ch_wv) { LGCN_CHECK_PTR(p.ch_v_out); LGCN_CHECK_ALIGN16(p.ch_wv); LGCN_CHECK_ALIGN16(p.ch_v_out); }
+    if ((p.ch_wu || p.ch_wv) && need_col) return LGCN_EINVAL;      // chained outputs: row blocks without CSR relations
     *need_col_out = need_col;
+    return LGCN_OK;
+}
+
+// The chained outputs of a block as launches of their own on its `out` rows (exact-f32 mode, whose kernels have no
+// chained stages): the same arithmetic, lanegcn.py:696-699.
+static int chain_as_launches(const lgcn_agg_mlp_t &p, void *stream) {
+    lgcn_agg_mlp_t q{};
+    q.n_rows = p.n_rows; q.n_rel = 1; q.eps = p.eps; q.mma = p.mma;
+    q.rel[0].src = p.out; q.rel[0].mode = LGCN_REL_IDENT;
+    if (p.ch_wu) {
+        q.rel[0].wp = p.ch_wq; q.flags = LGCN_F_GN1 | LGCN_F_RELU1 | LGCN_F_GEMM2;
+        q.gn1_g = p.ch_gq_g; q.gn1_b = p.ch_gq_b; q.wp2 = p.ch_wu; q.out = p.ch_u_out;
+        const int rc = lgcn_agg_mlp(&q, stream);
+        if (rc != LGCN_OK) return rc;
+    }
+    if (p.ch_wv) {
+        q.rel[0].wp = p.ch_wv; q.flags = 0; q.gn1_g = q.gn1_b = q.wp2 = nullptr; q.out = p.ch_v_out;
+        return lgcn_agg_mlp(&q, stream);
+    }
     return LGCN_OK;
 }
 
@@ -568,7 +596,27 @@ int lgcn_agg_mlp(const lgcn_agg_mlp_t *ph, void *stream) {
         hipLaunchKernelGGL((k_agg_mlp<1>), dim3(n_tiles), dim3(512), 0, (hipStream_t)stream, p, n_tiles);
     else
         hipLaunchKernelGGL((k_agg_mlp<0>), dim3(n_tiles), dim3(512), 0, (hipStream_t)stream, p, n_tiles);
-    return launch_status();
+    const int st = launch_status();
+    return st != LGCN_OK || !(p.ch_wu || p.ch_wv) ? st : chain_as_launches(p, stream);
+}
+
+int lgcn_agg_mlp_multi(const lgcn_agg_mlp_t *const *ps, int n, void *stream) {
+    LGCN_CHECK_PTR(ps);
+    if (n < 1 || n > LGCN_MAX_MULTI) return LGCN_EINVAL;
+    bool one = true;
+    for (int i = 0; i < n; ++i) {
+        LGCN_CHECK_PTR(ps[i]);
+        bool c = false;
+        const int rc = validate_agg(*ps[i], &c);
+        if (rc != LGCN_OK) return rc;
+        one = one && ps[i]->n_rows > 0 && ps[i]->mma == ps[0]->mma && ps[i]->mma != LGCN_MMA_F32 && !c && ps[i]->tile_rb == 0;
+    }
+    if (one && n > 1) return agg_mlp_multi_bf(ps, n, (hipStream_t)stream);
+    for (int i = 0; i < n; ++i) {
+        const int rc = lgcn_agg_mlp(ps[i], stream);
+        if (rc != LGCN_OK) return rc;
+    }
+    return LGCN_OK;
 }
 
 int lgcn_agg_mlp_pair(const lgcn_agg_mlp_t *a, const lgcn_agg_mlp_t *b, void *stream) {

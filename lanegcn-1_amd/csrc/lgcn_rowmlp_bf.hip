@@ -266,11 +266,13 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     // of its relation), (2) relation 0 when it is the row itself (LaneConv's ctr, every Linear: always
     // active, needs no index): its rows on the gather waves, its first weight fragments on the MFMA waves,
     // (3) the col entries, whose addresses depend on (1).  (1) and (2) share one round trip.
-    float *gnp = reinterpret_cast<float *>(smem + TL::SMEM + 128 + IX::INTS * 4);   // gn1 g|b, gn2 g|b
+    float *gnp = reinterpret_cast<float *>(smem + TL::SMEM + 128 + IX::INTS * 4);   // gn1 g|b, gn2 g|b, chained query g|b
+    const bool chain_u = KIND == 0 && p.ch_wu != nullptr, chain_v = KIND == 0 && p.ch_wv != nullptr;
     if (tid >= 128 && tid < 256) {
         const int c = tid - 128;
         if (flags & LGCN_F_GN1) { gnp[c] = p.gn1_g[c]; gnp[kC + c] = p.gn1_b[c]; }
         if (flags & LGCN_F_GN2) { gnp[2 * kC + c] = p.gn2_g[c]; gnp[3 * kC + c] = p.gn2_b[c]; }
+        if (chain_u) { gnp[4 * kC + c] = p.ch_gq_g[c]; gnp[5 * kC + c] = p.ch_gq_b[c]; }
     }
     const int len = nrc * 16 + 1;     // <= 257 ints per sub-tile: one per thread
     int c0[RB], c1[RB], rpv[RB], a0[RB], a1[RB];
@@ -427,6 +429,54 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
     const int64_t my_n = row0 + my_row;
     const bool my_live = my_has_row && my_n < p.n_rows;
     RowVals resv;     // residual row: requested here, used after GroupNorm (one stage) or after the second GEMM
+    // Chained outputs (lgcn.h: ch_*): the block's final rows y go back to LDS as operand planes instead of only to HBM:
+    //   u_out = ReLU(GN_q(y W_q^T)) W_u^T  (three more barriers-separated passes), v_out = y W_v^T (stored from the
+    //   accumulators: 64-byte row segments, by the otherwise idle MFMA waves).  Yp is free here: its last readers (the
+    //   second GEMM, or nobody) passed the barrier in front of the final row phase.
+    auto chained = [&](const RowVals &y) {
+        if (KIND != 0) return;
+        const uint4 *wq = reinterpret_cast<const uint4 *>(chain_u ? p.ch_wq : p.ch_wv);
+        if (my_has_row) row_split_store<F>(Yp, TL::PLANE, my_row, my_rt, y);
+        if (wave < 4) ring_prime<F>(bfrag, wq, wave, lane);
+        lds_barrier();
+        if (wave < 4) {
+            if (chain_u) {
+                acc_zero<RB>(acc);
+                gemm_pass<RB, F>(Yp, wq, reinterpret_cast<const uint4 *>(chain_v ? p.ch_wv : p.ch_wu), bfrag, wave, lane, acc);
+                acc_store<RB>(T, acc, lane, wave);      // T's readers (the final row phase) wrote Yp after reading it
+            }
+            if (chain_v) {
+                acc_zero<RB>(acc);
+                gemm_pass<RB, F>(Yp, reinterpret_cast<const uint4 *>(p.ch_wv), reinterpret_cast<const uint4 *>(chain_u ? p.ch_wu : nullptr),
+                                 bfrag, wave, lane, acc);
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int64_t n = row0 + 16 * rb + 4 * (lane >> 4) + i;
+                            if (n < p.n_rows) p.ch_v_out[n * kC + 32 * wave + 16 * cb + (lane & 15)] = acc[rb][cb][i];
+                        }
+            }
+        }
+        if (!chain_u) return;
+        lds_barrier();
+        if (my_has_row) {
+            RowVals r = row_load(T + (upper ? 32 : 0) * kLDA, my_rt);
+            row_gn(r, my_rt, gnp + 4 * kC, gnp + 5 * kC, p.eps);
+            row_relu(r);
+            row_split_store<F>(Yp, TL::PLANE, my_row, my_rt, r);      // Yp's readers passed the barrier above
+        }
+        lds_barrier();
+        if (wave < 4) {
+            acc_zero<RB>(acc);
+            gemm_pass<RB, F>(Yp, reinterpret_cast<const uint4 *>(p.ch_wu), nullptr, bfrag, wave, lane, acc);
+            acc_store<RB>(T, acc, lane, wave);
+        }
+        lds_barrier();
+        if (my_live) row_store_global(p.ch_u_out + my_n * kC, my_rt, row_load(T + (upper ? 32 : 0) * kLDA, my_rt));
+    };
     if (two && upper) gemm2_prefetch<F>(bfrag, reinterpret_cast<const uint4 *>(p.wp2), wave, lane);
     if (my_has_row) {
         {   // branch-free (row clamped, p.out read and ignored without a residual): behind a branch or a
@@ -446,8 +496,12 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
         if (two && my_live && p.out_mid) row_store_global(p.out_mid + my_n * kC, my_rt, r);
         if (two) row_split_store<F>(Yp, TL::PLANE, my_row, my_rt, r);
         else if (my_live) row_store_global(p.out + my_n * kC, my_rt, r);
+        if (!two && (chain_u || chain_v)) resv = r;      // the final rows (the residual is spent)
     }
-    if (!two) return;
+    if (!two) {
+        if (chain_u || chain_v) chained(resv);
+        return;
+    }
     LGCN_STAMP(42);
     lds_barrier();
     LGCN_STAMP(43);
@@ -466,8 +520,10 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
         if (my_live && (flags & LGCN_F_RES)) row_add(r, resv);
         if (flags & LGCN_F_RELU2) row_relu(r);
         if (my_live) row_store_global(p.out + my_n * kC, my_rt, r);
+        resv = r;
     }
     LGCN_STAMP(46);
+    if (chain_u || chain_v) chained(resv);
 }
 
 // Tiles of <= 32 rows must keep two 8-wave workgroups per CU (4 waves per SIMD = 128 VGPRs): that co-residency
@@ -478,7 +534,7 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
 
 template <int RB, int F, int KIND, bool DEEP>
 __global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, DEEP, F) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4 + 4 * kC * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4 + 6 * kC * 4];
     agg_body<RB, F, KIND, DEEP>(p, n_tiles, blockIdx.x, smem);
 }
 
@@ -487,9 +543,24 @@ __global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, DEEP, F) void k_agg_ml
 template <int RB, int F>
 __global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, false, F) void k_agg_mlp_bf2(const lgcn_agg_mlp_t pa, const lgcn_agg_mlp_t pb, int tiles_a,
                                                      int tiles_b) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4 + 4 * kC * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4 + 6 * kC * 4];
     if ((int)blockIdx.x < tiles_a) agg_body<RB, F, 0, false>(pa, tiles_a, blockIdx.x, smem);
     else agg_body<RB, F, 0, false>(pb, tiles_b, blockIdx.x - tiles_a, smem);
+}
+
+// Up to LGCN_MAX_MULTI independent row blocks in one launch (lgcn_agg_mlp_multi): the problems' tiles follow each other
+// in the grid; a workgroup reads its problem's arguments from the kernel-argument segment by index (scalar loads).
+struct MultiArgs {
+    lgcn_agg_mlp_t p[LGCN_MAX_MULTI];
+    int tiles[LGCN_MAX_MULTI];
+    int n;
+};
+template <int RB, int F>
+__global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, false, F) void k_agg_mlp_bfn(const MultiArgs m) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[Tile<RB, F>::SMEM + 128 + TileIdx<RB>::INTS * 4 + 6 * kC * 4];
+    int b = blockIdx.x, i = 0;
+    while (i + 1 < m.n && b >= m.tiles[i]) { b -= m.tiles[i]; ++i; }
+    agg_body<RB, F, 0, false>(m.p[i], m.tiles[i], b, smem);
 }
 
 template <int RB, int F>
@@ -715,6 +786,32 @@ int agg_mlp_pair_bf(const lgcn_agg_mlp_t &a, const lgcn_agg_mlp_t &b, hipStream_
     }
 #undef LGCN_AGG2_RB
 #undef LGCN_AGG2
+    return launch_status();
+}
+
+int agg_mlp_multi_bf(const lgcn_agg_mlp_t *const *ps, int n, hipStream_t st) {
+    // one tile height for all problems: the one picked for the largest
+    int64_t big = 0;
+    for (int i = 0; i < n; ++i) big = ps[i]->n_rows > big ? ps[i]->n_rows : big;
+    const int rb = pick_rb(big, fmt_of(ps[0]->mma));
+    const int rows = 16 * rb;
+    MultiArgs m{};
+    m.n = n;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        m.p[i] = *ps[i];
+        m.tiles[i] = (int)((ps[i]->n_rows + rows - 1) / rows);
+        total += m.tiles[i];
+    }
+#define LGCN_AGGN(RB_, F_) hipLaunchKernelGGL((k_agg_mlp_bfn<RB_, F_>), dim3(total), dim3(512), 0, st, m)
+#define LGCN_AGGN_RB(F_) switch (rb) { case 1: LGCN_AGGN(1, F_); break; case 2: LGCN_AGGN(2, F_); break; case 3: LGCN_AGGN(3, F_); break; default: LGCN_AGGN(4, F_); }
+    switch (fmt_of(ps[0]->mma)) {
+        case 0: LGCN_AGGN_RB(0); break;
+        case 1: LGCN_AGGN_RB(1); break;
+        default: LGCN_AGGN_RB(2); break;
+    }
+#undef LGCN_AGGN_RB
+#undef LGCN_AGGN
     return launch_status();
 }
 

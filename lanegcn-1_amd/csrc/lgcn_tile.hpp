@@ -122,6 +122,7 @@ struct PairParams {
 // split-bf16 implementations (lgcn_rowmlp_bf.hip)
 int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st);
 int agg_mlp_pair_bf(const lgcn_agg_mlp_t &a, const lgcn_agg_mlp_t &b, hipStream_t st);
+int agg_mlp_multi_bf(const lgcn_agg_mlp_t *const *ps, int n, hipStream_t st);
 int mapnet_input_bf(const InputParams &p, int mma, hipStream_t st);
 int att_pairs_bf(const PairParams &p, int mma, hipStream_t st);
 int pack_weight_bf(const float *W, int ld, int mma, int transpose, void *out, hipStream_t st);

@@ -47,26 +47,63 @@ def from_numpy(data):
 class Batch(dict):
     """The reference's batch -- a dict of per-scene lists (data.py:555-561) -- that also carries, as an ATTRIBUTE
     (the dict's keys stay exactly the reference's), the same scenes packed for the device: ``flat`` =
-    (engine.HostFlatBatch, (actor tracks, rot, orig, actors per scene))."""
-    flat = None
+    (engine.HostFlatBatch, (actor tracks, rot, orig, actors per scene)).  The packed copy is built on first use
+    (Net.forward under no_grad) and kept; ``collate_fn(..., pack=True)`` builds it at collate time, i.e. in the
+    DataLoader worker.  Training batches never read it and never pay for it."""
+    _scenes = None       # the collated scenes (torch leaves), kept for the lazy pack
+    _flat = None
+    _flat_tried = False
+
+    @property
+    def flat(self):
+        if self._flat is None and not self._flat_tried and self._scenes is not None:
+            self._flat_tried = True
+            self._flat = _pack(self._scenes)
+            self._scenes = None
+        return self._flat
+
+    @flat.setter
+    def flat(self, value):
+        self._flat, self._flat_tried = value, True
 
 
-def collate_fn(batch):
-    """list of scene dicts -> dict of per-key lists, no padding (reference data.py:555-561).  The packed copy
-    (Batch.flat: one staging buffer) is built here -- i.e. in the DataLoader worker when there is one -- so that
-    Net.forward(data) under no_grad starts with one host-to-device copy instead of a host collate."""
-    raw = batch
-    batch = from_numpy(batch)
-    out = Batch({k: [scene[k] for scene in batch] for k in batch[0].keys()})
+_pack_warned = [False]
+
+
+def _pack(scenes):
+    """(HostFlatBatch, host actor inputs) of a list of scenes, or None (with ONE warning per process) when the scenes do
+    not have the packed layout's fields or the pack fails -- Net.forward then collates the dict-of-lists batch itself."""
+    if len(scenes) == 0 or not all(k in scenes[0] for k in ("graph", "feats", "ctrs", "rot", "orig")):
+        return None
     try:
         from .engine import collate_flat_host, host_actor_inputs
-        if len(raw) > 0 and all(k in raw[0] for k in ("graph", "feats", "ctrs", "rot", "orig")):
-            # pinned staging only in a process that already talks to the GPU (never initialise it in a loader worker)
-            pin = torch.cuda.is_available() and torch.cuda.is_initialized() and torch.utils.data.get_worker_info() is None
-            out.flat = (collate_flat_host(raw, pin=pin), host_actor_inputs(raw))
-    except Exception:      # noqa: BLE001 -- the packed copy is an accelerator, never a requirement
-        out.flat = None
+        # pinned staging only in a process that already talks to the GPU (never initialise it in a loader worker)
+        pin = torch.cuda.is_available() and torch.cuda.is_initialized() and torch.utils.data.get_worker_info() is None
+        return (collate_flat_host(scenes, pin=pin), host_actor_inputs(scenes))
+    except Exception as e:      # noqa: BLE001 -- the packed copy is an accelerator, never a requirement
+        if not _pack_warned[0]:
+            _pack_warned[0] = True
+            import warnings
+            warnings.warn("lanegcn_amd.data: packing a batch for the device failed (%r); Net.forward will collate it "
+                          "per call instead" % (e,))
+        return None
+
+
+def collate_fn(batch, pack: bool = False):
+    """list of scene dicts -> dict of per-key lists, no padding (reference data.py:555-561).  pack=True also builds the
+    packed copy (Batch.flat: one staging buffer) here -- in the DataLoader worker when there is one -- so that
+    Net.forward(data) under no_grad starts with one host-to-device copy; by default it is built on first use."""
+    batch = from_numpy(batch)
+    out = Batch({k: [scene[k] for scene in batch] for k in batch[0].keys()})
+    out._scenes = batch
+    if pack:
+        out.flat        # noqa: B018 -- builds and caches it
     return out
+
+
+def collate_fn_packed(batch):
+    """collate_fn for evaluation loaders: the packed copy is built in the loader."""
+    return collate_fn(batch, pack=True)
 
 
 # ---------------------------------------------------------------- synthetic scenes

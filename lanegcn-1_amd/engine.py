@@ -245,11 +245,15 @@ class HotPathEngine:
         if stages:
             out["map_net"] = feat
         # A2M (lanegcn.py:385-407)
-        feat = self.a2m.fuse_meta(feat, fb.turn, fb.control, fb.intersect)
-        if side is not None:
-            main.wait_stream(side)            # the pair sets are needed from here on
-        for att in self.a2m.att:
-            feat = att.run(feat, actors, pairs[0], side)
+        fold = side is None and M._fold_ok(actors) and fb.n_nodes > 0
+        if fold:      # launches folded across the Att layers of the three blocks (lanegcn.att_block): 8 row-block launches
+            feat = self.a2m.run(feat, fb.turn, fb.control, fb.intersect, actors, pairs[0])
+        else:
+            feat = self.a2m.fuse_meta(feat, fb.turn, fb.control, fb.intersect)
+            if side is not None:
+                main.wait_stream(side)            # the pair sets are needed from here on
+            for att in self.a2m.att:
+                feat = att.run(feat, actors, pairs[0], side)
         if stages:
             out["a2m"] = feat
         # M2M (lanegcn.py:445-480)
@@ -258,13 +262,20 @@ class HotPathEngine:
             out["m2m"] = feat
         # M2A (lanegcn.py:502-513)
         act = actors
-        for att in self.m2a.att:
-            act = att.run(act, feat, pairs[1], side)
-        if stages:
-            out["m2a"] = act
-        # A2A (lanegcn.py:534-545)
-        for att in self.a2a.att:
-            act = att.run(act, act, pairs[2], side)
+        if fold:
+            # M2A's last tail also emits U / V of A2A's first layer (its targets and context are M2A's output rows)
+            act, uv = M.att_block(self.m2a.att, act, feat, pairs[1], next_att=self.a2a.att[0], next_ctx_is_out=True)
+            if stages:
+                out["m2a"] = act
+            act, _ = M.att_block(self.a2a.att, act, act, pairs[2], uv=uv, ctx_is_agts=True)
+        else:
+            for att in self.m2a.att:
+                act = att.run(act, feat, pairs[1], side)
+            if stages:
+                out["m2a"] = act
+            # A2A (lanegcn.py:534-545)
+            for att in self.a2a.att:
+                act = att.run(act, act, pairs[2], side)
         if stages:
             out["a2a"] = act
         out["nodes"], out["actors"] = feat, act
@@ -314,22 +325,26 @@ class HotPathEngine:
                                       fb.num_scales, impl=self.lane_impl)
 
         def a2m():
-            feat = self.a2m.fuse_meta(st["nodes"], fb.turn, fb.control, fb.intersect)
-            for att in self.a2m.att:
-                feat = att.run(feat, actors, st["pairs"][0])
-            st["nodes_a2m"] = feat
+            st["nodes_a2m"] = self.a2m.run(st["nodes"], fb.turn, fb.control, fb.intersect, actors, st["pairs"][0])
 
         def m2m():
             st["nodes_m2m"] = M.lane_conv(self.m2m.fuse, st["nodes_a2m"], st["plan"], fb.num_scales, impl=self.lane_impl)
 
-        def m2a():
+        def m2a():      # as in forward(): the last tail also emits A2A's first U / V
+            if M._fold_ok(st["nodes_m2m"]):
+                st["actors_m2a"], st["uv_a2a"] = M.att_block(self.m2a.att, actors, st["nodes_m2m"], st["pairs"][1],
+                                                             next_att=self.a2a.att[0], next_ctx_is_out=True)
+                return
             act = actors
             for att in self.m2a.att:
                 act = att.run(act, st["nodes_m2m"], st["pairs"][1])
-            st["actors_m2a"] = act
+            st["actors_m2a"], st["uv_a2a"] = act, None
 
         def a2a():
             act = st["actors_m2a"]
+            if M._fold_ok(act):
+                st["actors_a2a"] = M.att_block(self.a2a.att, act, act, st["pairs"][2], uv=st["uv_a2a"], ctx_is_agts=True)[0]
+                return
             for att in self.a2a.att:
                 act = att.run(act, act, st["pairs"][2])
             st["actors_a2a"] = act
@@ -414,7 +429,8 @@ class FullNetEngine:
             res["n_pairs"] = hot["n_pairs"]     # device counts of the three pair sets (A2M, M2A, A2A)
         return res
 
-    def capture(self, fb, actor_feats, rot, orig, sizes, warmup: int = 3, tune_convs: bool = True, **fwd_kw):
+    def capture(self, fb, actor_feats, rot, orig, sizes, warmup: int = 3, tune_convs: bool = True,
+                capture_error_mode: str = "global", **fwd_kw):
         """Capture the whole Net forward.  tune_convs: let MIOpen search its solvers for ActorNet's 17 Conv1d shapes
         during the warm-up (torch.backends.cudnn.benchmark): the shapes of a captured graph are fixed, and the
         default heuristic picks were measured 11 % slower end to end (2.34 vs 2.10 ms per batch)."""
@@ -430,7 +446,7 @@ class FullNetEngine:
             torch.cuda.synchronize()
             with self.hot.own_counters(fb) as cnt:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode=capture_error_mode):
                     out = self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
             graph._lgcn_inputs = (fb, actor_feats, rot, orig, cnt)      # the graph holds their addresses: keep them alive
         finally:

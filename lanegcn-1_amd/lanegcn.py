@@ -331,6 +331,7 @@ class Att(nn.Module):
     P per pair set; the benchmark engine switches it off to run sync-free."""
     strict = True
     legacy_offsets = True   # zero-pair scenes do not advance hi/wi offsets (lanegcn.py:681-687)
+    fold = os.environ.get("LGCN_ATT_FOLD", "1") != "0"      # att_block: row-block launches folded across the Att layers
 
     def __init__(self, n_agt: int, n_ctx: int) -> None:
         super().__init__()
@@ -429,6 +430,98 @@ class Att(nn.Module):
                            tag="att_post")
 
 
+    # ---- the pieces of run(), for att_block (launch folding across the Att layers of a fusion block)
+    def u_kw(self, agts: Tensor) -> dict:
+        """U = ReLU(GN_q(agts W_q^T)) W_c0[:,128:256]^T per target row, as an agg_mlp problem."""
+        return dict(n_rows=agts.shape[0], rels=[ops.RelSpec(agts, ops.packed(self.query.linear.weight))],
+                    flags=L.F_GN1 | L.F_RELU1 | L.F_GEMM2, gn1=_gn(self.query.norm),
+                    wp2=ops.packed(self.ctx[0].linear.weight, 128, 128), eps=self.query.norm.eps)
+
+    def v_kw(self, ctx: Tensor) -> dict:
+        """V = ctx W_c0[:,256:384]^T per context row, as an agg_mlp problem."""
+        return dict(n_rows=ctx.shape[0], rels=[ops.RelSpec(ctx, ops.packed(self.ctx[0].linear.weight, 256, 128))], flags=0)
+
+    def chain_u(self):
+        """What a row block that PRODUCES this layer's target rows needs to emit its U as well (ops.agg_mlp chain_u)."""
+        return (ops.packed(self.query.linear.weight), _gn(self.query.norm), ops.packed(self.ctx[0].linear.weight, 128, 128))
+
+    def chain_v(self):
+        return ops.packed(self.ctx[0].linear.weight, 256, 128)
+
+    def pairs_tail(self, agts: Tensor, n_ctx: int, ps: ops.PairSet, U: Tensor, V: Tensor, chain_u=None, chain_v=None):
+        """Pair MLP + segment sum + node epilogue for given U / V (lanegcn.py:693-709); the tail's launch can emit the
+        NEXT layer's U / V from its output rows (chain_u / chain_v).  Returns out or (out, U'[, V'])."""
+        T = agts.shape[0]
+        lin, c0 = self.linear, self.ctx[0]
+        seg = 16 if ops.att_pairs_impl() == "ws" and n_ctx >= T else 0
+        m = ops.att_pairs(ps, self.dist[0].weight, self.dist[0].bias, ops.packed(self.dist[2].linear.weight),
+                          _gn(self.dist[2].norm), ops.packed(c0.linear.weight, 0, 128), U, V, _gn(c0.norm),
+                          eps=c0.norm.eps, seg=seg)
+        rels = [ops.RelSpec(agts, ops.packed(self.agt.weight)),
+                ops.RelSpec(m, ops.packed(self.ctx[1].weight), L.REL_RANGE16 if seg else L.REL_RANGE)]
+        return ops.agg_mlp(T, rels, _FULL, rowptr=ps.rowptr, gn1=_gn(self.norm),
+                           wp2=ops.packed(lin.linear.weight), gn2=_gn(lin.norm), res=agts, eps=self.norm.eps,
+                           tag="att_post", chain_u=chain_u, chain_v=chain_v)
+
+
+def att_block(atts, agts: Optional[Tensor], ctx: Tensor, ps: ops.PairSet, head: Optional[dict] = None, uv=None,
+              ctx_is_agts: bool = False, next_att: Optional["Att"] = None, next_ctx_is_out: bool = False):
+    """The Att layers of one fusion block (reference lanegcn.py:397-406, 506-512, 537-544) with the row-block launches
+    folded: a layer's tail also emits the next layer's U (and V, when the context rows are the targets: A2A) from its
+    output rows before they leave the CU, the V rows of every layer whose context does not change are computed up
+    front, and the block's first launch carries them together with U of layer 0 -- chained onto `head`, the row block
+    that produces the targets (A2M.meta), when there is one.  Same arithmetic as Att.run per layer.
+      head: agg_mlp keywords of a row block whose output is the block's target rows (agts is then ignored);
+      uv: (U, V) of layer 0 when a previous block's tail has already emitted them;
+      next_att: first Att of the FOLLOWING block when this block's output rows are its targets (and, with
+                next_ctx_is_out, its context rows): the last tail emits its U (and V).
+    Returns (out, uv_next) -- uv_next is None without next_att."""
+    n = len(atts)
+    Vs = [None] * n
+    if uv is not None:
+        U, Vs[0] = uv
+    else:
+        first = dict(head, chain_u=atts[0].chain_u()) if head is not None else atts[0].u_kw(agts)
+        probs = [first] + [atts[i].v_kw(ctx) for i in range(1 if ctx_is_agts else n)]
+        res = ops.agg_mlp_multi(probs, tag="att_head")
+        if head is not None:
+            agts, U = res[0]
+        else:
+            U = res[0]
+        for i in range(len(probs) - 1):
+            Vs[i] = res[1 + i]
+    if not ctx_is_agts and any(v is None for v in Vs):      # layer 0's V came with uv: the later layers' V on their own
+        todo = [i for i in range(n) if Vs[i] is None]
+        for i, v in zip(todo, ops.agg_mlp_multi([atts[i].v_kw(ctx) for i in todo], tag="att_head")):
+            Vs[i] = v
+    uv_next = None
+    for i, att in enumerate(atts):
+        nxt = atts[i + 1] if i + 1 < n else next_att
+        want_v = nxt is not None and (ctx_is_agts if i + 1 < n else next_ctx_is_out)
+        n_ctx = agts.shape[0] if ctx_is_agts else ctx.shape[0]
+        res = att.pairs_tail(agts, n_ctx, ps, U, Vs[i], chain_u=nxt.chain_u() if nxt is not None else None,
+                             chain_v=nxt.chain_v() if want_v else None)
+        if nxt is None:
+            agts = res
+        elif i + 1 < n:
+            agts, U = res[0], res[1]
+            if want_v:
+                Vs[i + 1] = res[2]
+        else:
+            agts, uv_next = res[0], (res[1], res[2] if want_v else None)
+    return agts, uv_next
+
+
+def _fold_ok(ctx: Tensor) -> bool:
+    return Att.fold and ops.att_impl() != "fused" and ctx.shape[0] > 0
+
+
+def _strict_check(ps: ops.PairSet):
+    """Att.strict: a batch without a single pair raises like torch.cat([]) at lanegcn.py:688 (one host read of P)."""
+    if Att.strict and ps.count() == 0:
+        raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
+
+
 class A2M(nn.Module):
     """Actor to Map fusion (reference lanegcn.py:366-407)."""
 
@@ -442,10 +535,21 @@ class A2M(nn.Module):
     def fuse_meta(self, feat: Tensor, turn: Tensor, control: Tensor, intersect: Tensor) -> Tensor:
         """meta = Linear(132 -> 128)+GN+ReLU over cat(feat, turn, control, intersect) without
         materialising the cat (reference lanegcn.py:387-395)."""
+        return ops.agg_mlp(**self.meta_kw(feat, turn, control, intersect))
+
+    def meta_kw(self, feat: Tensor, turn: Tensor, control: Tensor, intersect: Tensor) -> dict:
         w = self.meta.linear.weight
-        return ops.agg_mlp(feat.shape[0], [ops.RelSpec(feat, ops.packed(w, 0, 128))], L.F_GN1 | L.F_RELU1,
-                           x4=(turn, control, intersect), w4=ops.cols4(w, 128),
-                           gn1=_gn(self.meta.norm), eps=self.meta.norm.eps)
+        return dict(n_rows=feat.shape[0], rels=[ops.RelSpec(feat, ops.packed(w, 0, 128))], flags=L.F_GN1 | L.F_RELU1,
+                    x4=(turn, control, intersect), w4=ops.cols4(w, 128), gn1=_gn(self.meta.norm), eps=self.meta.norm.eps)
+
+    def run(self, feat: Tensor, turn: Tensor, control: Tensor, intersect: Tensor, actors: Tensor, ps: ops.PairSet) -> Tensor:
+        """meta + both Att layers for given pairs, launches folded (att_block): inference only."""
+        if not _fold_ok(actors):
+            feat = self.fuse_meta(feat, turn, control, intersect)
+            for att in self.att:
+                feat = att.run(feat, actors, ps)
+            return feat
+        return att_block(self.att, None, actors, ps, head=self.meta_kw(feat, turn, control, intersect))[0]
 
     def forward(self, feat: Tensor, graph: Dict, actors: Tensor, actor_idcs: List[Tensor],
                 actor_ctrs: List[Tensor]) -> Tensor:
@@ -455,6 +559,11 @@ class A2M(nn.Module):
             feat = A.gn_act(A.linear_gn(feat, w, col0=0) + F.linear(meta4, w[:, 128:132]), gn=self.meta.norm, relu=True)
         else:
             x_in = feat
+            if len(actors) > 0 and _fold_ok(actors):      # inference: meta + both Att layers with folded launches
+                ps = build_pairs(graph["idcs"], graph["ctrs"], actor_idcs, actor_ctrs, self.config["actor2map_dist"],
+                                 Att.legacy_offsets)
+                _strict_check(ps)
+                return ops.guarded(lambda: self.run(x_in, graph["turn"], graph["control"], graph["intersect"], actors, ps))
             feat = ops.guarded(lambda: self.fuse_meta(x_in, graph["turn"], graph["control"], graph["intersect"]))
         th = self.config["actor2map_dist"]
         ps = None
@@ -479,6 +588,10 @@ class M2A(nn.Module):
         ps = None
         if len(nodes) > 0:
             ps = build_pairs(actor_idcs, actor_ctrs, node_idcs, node_ctrs, th, Att.legacy_offsets)
+            if _fold_ok(nodes) and not _hot_guard(actors, nodes, *ops.module_params(self)):
+                _strict_check(ps)
+                x_in = actors
+                return ops.guarded(lambda: att_block(self.att, x_in, nodes, ps)[0])
         for att in self.att:
             actors = att(actors, actor_idcs, actor_ctrs, nodes, node_idcs, node_ctrs, th, pairs=ps)
         return actors
@@ -497,6 +610,10 @@ class A2A(nn.Module):
         ps = None
         if len(actors) > 0:
             ps = build_pairs(actor_idcs, actor_ctrs, actor_idcs, actor_ctrs, th, Att.legacy_offsets)
+            if _fold_ok(actors) and not _hot_guard(actors, *ops.module_params(self)):
+                _strict_check(ps)
+                x_in = actors
+                return ops.guarded(lambda: att_block(self.att, x_in, x_in, ps, ctx_is_agts=True)[0])
         for att in self.att:
             actors = att(actors, actor_idcs, actor_ctrs, actors, actor_idcs, actor_ctrs, th, pairs=ps)
         return actors
@@ -602,7 +719,10 @@ class ActorNet(nn.Module):
         return res1d(self.output, out)[:, -1, :].contiguous()        # a view would be copied again by every op that takes it
 
     def _hip_ok(self, actors: Tensor) -> bool:
-        if ActorNet.impl != "hip" or not self._channels_last_ok(actors):
+        # lgcn_conv1d_gn / lgcn_res1d_gn take no matrix-mode argument: they always split operands into two fp16 planes.
+        # In the exact-f32 and bf16x3 modes (and inside the range guard's bf16x3 re-run, which must cure an overflow that
+        # starts in ActorNet too) the MIOpen channels-last path runs instead.
+        if ActorNet.impl != "hip" or ops.get_mma() != "f16x2" or not self._channels_last_ok(actors):
             return False
         convs = [c for g in self.groups for b in g for c in ([b.conv1, b.conv2] + ([b.downsample[0]] if b.downsample is not None else []))]
         convs += [l.conv for l in self.lateral] + [self.output.conv1, self.output.conv2]
@@ -739,6 +859,14 @@ class PredNet(nn.Module):
         return {"cls": [cls[i] for i in actor_idcs], "reg": [reg[i] for i in actor_idcs]}
 
 
+def _own_outputs(gout: Dict) -> Dict:
+    """cls / reg of a replayed whole-Net graph live in the graph's static pool: the next replay overwrites them.  The
+    caller gets copies (two small device-to-device copies), like the fresh tensors every other path returns."""
+    out = dict(gout)
+    out["cls"], out["reg"] = gout["cls"].clone(), gout["reg"].clone()
+    return out
+
+
 def _net_replay_or_run(self, eng, hfb, feats, rot, orig, sizes):
     """Whole-Net forward for one host-packed batch (engine.HostFlatBatch + host actor tensors).  A batch whose shapes
     (and the weights' versions) equal the previous call's is captured in a hipGraph once and replayed from then on
@@ -755,7 +883,7 @@ def _net_replay_or_run(self, eng, hfb, feats, rot, orig, sizes):
         for dst, src in zip(gin, (feats, rot, orig)):
             dst.copy_(src, non_blocking=True)
         g.replay()
-        return gfb, gout
+        return gfb, _own_outputs(gout)
     fb = hfb.to()
     dev = fb.node_ctrs.device
     ns = fb.num_scales
@@ -763,10 +891,12 @@ def _net_replay_or_run(self, eng, hfb, feats, rot, orig, sizes):
         raise KeyError("node_idcs")
     gin = tuple(t.to(dev, non_blocking=True) for t in (feats, rot, orig))
     if Net.graph_cache and st["last"] == sig:      # second time in a row: worth capturing
-        g, gout = eng.capture(fb, *gin, sizes, warmup=1, tune_convs=False, return_pairs=Att.strict)
+        # thread_local: CUDA activity of OTHER threads (a DataLoader's pin_memory thread) must not abort the capture
+        g, gout = eng.capture(fb, *gin, sizes, warmup=1, tune_convs=False, return_pairs=Att.strict,
+                              capture_error_mode="thread_local")
         st.update(sig=sig, graph=(g, fb, gin, gout))
         g.replay()
-        return fb, gout
+        return fb, _own_outputs(gout)
     st["last"] = sig
     return fb, eng.forward(fb, *gin, sizes, return_pairs=Att.strict)
 
@@ -845,6 +975,9 @@ class Net(nn.Module):
             dev = fb.node_ctrs.device
             with ops.mma_scope("bf16x3"):
                 out = eng.forward(fb, feats.to(dev), rot.to(dev), orig.to(dev), sizes, return_pairs=Att.strict)
+            # the re-run has fp32's exponent range in every stage (ActorNet takes the MIOpen path outside f16x2, see
+            # ActorNet._hip_ok): non-finite values that survive it were in the inputs or the weights, and are returned as
+            # they are -- what the reference does with them
             host = [0] + (torch.stack(out["n_pairs"]).flatten().tolist() if Att.strict else [])
         if Att.strict and any(int(c) == 0 for c in host[1:]):
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")

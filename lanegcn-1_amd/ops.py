@@ -718,8 +718,10 @@ class RelSpec:
 
 def _agg_params(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None, col=None, n_rel_csr=0,
                 gn1=None, wp2=None, gn2=None, res=None, x4=None, w4=None, out=None, out_pre=None, out_mid=None,
-                out_pre2=None, eps=EPS, tile_rb=0):
-    """Fill one lgcn_agg_mlp_t.  Returns (struct, tensors to keep alive until the launch is enqueued, out)."""
+                out_pre2=None, eps=EPS, tile_rb=0, chain_u=None, chain_v=None):
+    """Fill one lgcn_agg_mlp_t.  Returns (struct, tensors to keep alive until the launch is enqueued, out).
+    chain_u = (wq packed, (gamma, beta), wu packed): also ReLU(GN_q(out wq^T)) wu^T -> out becomes (out, U[, V]);
+    chain_v = wv packed: also out wv^T (lgcn.h: the chained outputs of a row block)."""
     if not rels or len(rels) > L.MAX_REL:
         raise L.LgcnError("agg_mlp: 1..%d relations" % L.MAX_REL)
     dev = rels[0].src.device
@@ -754,6 +756,20 @@ def _agg_params(n_rows: int, rels: Sequence[RelSpec], flags: int, *, rowptr=None
     p.out_pre = 0 if out_pre is None else out_pre.data_ptr()
     p.out_mid = 0 if out_mid is None else out_mid.data_ptr()
     p.out_pre2 = 0 if out_pre2 is None else out_pre2.data_ptr()
+    if chain_u is not None or chain_v is not None:
+        outs = [out]
+        if chain_u is not None:
+            wq, gq, wu = chain_u
+            u = torch.empty((n_rows, C_FEAT), dtype=torch.float32, device=dev)
+            keep += [wq, gq[0], gq[1], wu]
+            p.ch_wq, p.ch_gq_g, p.ch_gq_b, p.ch_wu, p.ch_u_out = wq.data_ptr(), gq[0].data_ptr(), gq[1].data_ptr(), wu.data_ptr(), u.data_ptr()
+            outs.append(u)
+        if chain_v is not None:
+            v = torch.empty((n_rows, C_FEAT), dtype=torch.float32, device=dev)
+            keep.append(chain_v)
+            p.ch_wv, p.ch_v_out = chain_v.data_ptr(), v.data_ptr()
+            outs.append(v)
+        out = tuple(outs)
     return p, keep, out
 
 
@@ -776,6 +792,17 @@ def agg_mlp_pair(a: dict, b: dict, tag=None):
     with _Timed(tag):
         L.check(lib.lgcn_agg_mlp_pair(C.byref(pa), C.byref(pb), _stream()), "lgcn_agg_mlp_pair")
     return oa, ob
+
+
+def agg_mlp_multi(problems: Sequence[dict], tag=None):
+    """Up to 4 independent row blocks in one launch (lgcn_agg_mlp_multi).  problems: keyword dicts of agg_mlp.
+    Returns their outputs in order (a tuple per problem with chained outputs)."""
+    lib = L.load()
+    built = [_agg_params(**kw) for kw in problems]
+    arr = (C.POINTER(L.AggMlp) * len(built))(*[C.pointer(b[0]) for b in built])
+    with _Timed(tag):
+        L.check(lib.lgcn_agg_mlp_multi(arr, len(built), _stream()), "lgcn_agg_mlp_multi")
+    return [b[2] for b in built]
 
 
 # ------------------------------------------------------------------ LaneConv (gather-free, weight-stationary)

@@ -1030,3 +1030,68 @@ def test_net_forward_graph_cache(golden, ref_state_names, hip):
         net.pred_net.cls[1].weight.add_(0.01)                     # a weight changed: replaying would be stale
         o5 = net(batch)
         assert not torch.equal(o5["cls"][0], keep[1][0])
+
+
+# ------------------------------------------------------------------ round 3: folded row-block launches of the Att blocks
+def test_chained_outputs_and_multi_launch_equal_separate_launches(hip):
+    """lgcn_agg_mlp's chained outputs (ch_*: the NEXT Att layer's U / V computed from a row block's output rows before
+    they leave the CU) and lgcn_agg_mlp_multi (several row blocks in one launch) give bit for bit what separate
+    launches give -- ragged row counts, one- and two-stage blocks, U only / V only / both."""
+    M, ops = hip
+    from lanegcn_amd import _lib as L
+    g = torch.Generator().manual_seed(5)
+    w = lambda: ops.packed((torch.randn(128, 128, generator=g) * 0.09).cuda())
+    gn = lambda: ((1 + 0.1 * torch.randn(128, generator=g)).cuda(), (0.1 * torch.randn(128, generator=g)).cuda())
+    full = L.F_GN1 | L.F_RELU1 | L.F_GEMM2 | L.F_GN2 | L.F_RES | L.F_RELU2
+    for n_rows in (1, 37, 250, 1041):
+        x = torch.randn(n_rows, 128, generator=g).cuda()
+        w1, w2, wq, wu, wv, g1, g2, gq = w(), w(), w(), w(), w(), gn(), gn(), gn()
+        for flags, kw in ((full, dict(gn1=g1, wp2=w2, gn2=g2, res=x)), (L.F_GN1 | L.F_RELU1, dict(gn1=g1)), (0, {})):
+            base = ops.agg_mlp(n_rows, [ops.RelSpec(x, w1)], flags, **kw)
+            u_sep = ops.agg_mlp(n_rows, [ops.RelSpec(base, wq)], L.F_GN1 | L.F_RELU1 | L.F_GEMM2, gn1=gq, wp2=wu)
+            v_sep = ops.agg_mlp(n_rows, [ops.RelSpec(base, wv)], 0)
+            for cu, cv in ((True, False), (False, True), (True, True)):
+                res = ops.agg_mlp(n_rows, [ops.RelSpec(x, w1)], flags, chain_u=(wq, gq, wu) if cu else None,
+                                  chain_v=wv if cv else None, **kw)
+                assert torch.equal(res[0], base), (n_rows, flags, cu, cv)
+                if cu:
+                    assert torch.equal(res[1], u_sep), (n_rows, flags, cu, cv)
+                if cv:
+                    assert torch.equal(res[-1], v_sep), (n_rows, flags, cu, cv)
+    # several problems of different heights in one launch, one of them with chained outputs
+    xa, xb, xc = (torch.randn(n, 128, generator=g).cuda() for n in (700, 33, 129))
+    w1, w2, w3, wq, wu, g1, gq = w(), w(), w(), w(), w(), gn(), gn()
+    pa = dict(n_rows=700, rels=[ops.RelSpec(xa, w1)], flags=L.F_GN1 | L.F_RELU1, gn1=g1, chain_u=(wq, gq, wu))
+    pb = dict(n_rows=33, rels=[ops.RelSpec(xb, w2)], flags=0)
+    pc = dict(n_rows=129, rels=[ops.RelSpec(xc, w3)], flags=0)
+    for probs in ([pa, pb, pc], [pb, pa], [pc, pb, pa, pb]):
+        got = ops.agg_mlp_multi(probs)
+        for q, o in zip(probs, got):
+            want = ops.agg_mlp(**q)
+            if isinstance(want, tuple):
+                assert all(torch.equal(a, b) for a, b in zip(o, want))
+            else:
+                assert torch.equal(o, want)
+
+
+def test_folded_att_blocks_equal_per_layer_launches(gcase, hip):
+    """lanegcn.att_block (a layer's tail emits the next layer's U / V, V rows up front, A2M.meta chained into the first
+    U, M2A's last tail feeding A2A) against Att.run layer by layer: bit for bit, on the reference's fixture scenes
+    (incl. the scene without A2M pairs) and through the engine."""
+    M, ops = hip
+    from lanegcn_amd.engine import HotPathEngine, collate_flat
+    scenes, sd, mods = gcase
+    fb = collate_flat(scenes)
+    actors = torch.from_numpy(np.random.default_rng(4).normal(0, 1, (fb.n_actors, 128)).astype(np.float32)).relu().cuda()
+    eng = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"])
+    prev = M.Att.fold
+    try:
+        M.Att.fold = True
+        got = eng.forward(fb, actors, stages=True)
+        M.Att.fold = False
+        want = eng.forward(fb, actors, stages=True)
+    finally:
+        M.Att.fold = prev
+    torch.cuda.synchronize()
+    for k in ("map_net", "a2m", "m2m", "m2a", "a2a"):
+        assert torch.equal(got[k], want[k]), k

@@ -40,10 +40,12 @@ def test_version_and_strerror(lib):
 
 def test_struct_layout_matches_header(lib):
     _, mod = lib
-    # lgcn_rel_t: 2 pointers + 2 int32; lgcn_agg_mlp_t: 24-byte head, 16 rels, 14 pointers
+    # lgcn_rel_t: 2 pointers + 2 int32; lgcn_agg_mlp_t: 32-byte head, 16 rels, 16 + 7 pointers (the library
+    # static_asserts the same number: csrc/lgcn_rowmlp.hip)
     assert C.sizeof(mod.Rel) == 24
     assert mod.AggMlp.rel.offset == 32
-    assert C.sizeof(mod.AggMlp) == 32 + 16 * 24 + 16 * 8
+    assert C.sizeof(mod.AggMlp) == 32 + 16 * 24 + 23 * 8
+    assert mod.AggMlp.ch_wq.offset == 32 + 16 * 24 + 16 * 8
 
 
 def test_size_helpers(lib):
