@@ -370,6 +370,47 @@ def lanes_streams(n):
     return _LANE_STREAMS[:n]
 
 
+def config2_mapnet_s1(mods, dev, reps=30):
+    """BASELINE config 2 in the same line: MapNet only (graph_gather + CSR plan + stem + 4 LaneConv) on workload S1, one
+    merged lane graph of 10,008 nodes / 59,952 edges, in the headline mode and in exact f32 (the config says fp32): one
+    forward per replay, captured in a hipGraph, `reps` replays between one HIP event pair."""
+    from lanegcn_amd import data as gen
+    from lanegcn_amd import ops
+    from lanegcn_amd.engine import HotPathEngine, collate_flat
+    prev = ops.get_mma()
+    out = {}
+    try:
+        scenes = gen.synth_batch("S1", seed=100)
+        fb = collate_flat(scenes, dev)
+        actors = torch.zeros(fb.n_actors, C, device=dev)
+        flops, byts = laneconv_algorithmic(fb.n_nodes, sum(fb.n_edges))
+        out["workload"] = "S1: MapNet only, %d lane nodes, %d edges, one graph" % (fb.n_nodes, sum(fb.n_edges))
+        for mma in (prev, "f32") if prev != "f32" else ("f32",):
+            ops.set_mma(mma)
+            eng = HotPathEngine(mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"])
+            g, _ = eng.capture(fb, actors, mapnet_only=True)
+            for _ in range(3):
+                g.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / reps
+            # the four LaneConv layers alone
+            feat = eng.map_net.stem(fb.node_ctrs, fb.node_feats)
+            lc_us, _ = laneconv_launch_us(eng, fb, feat, feat, "fused" if mma in ("f32", "bf16x3") else "tiled")
+            out[mma] = {"mapnet_forward_us": us, "mapnet_forwards_per_s": 1e6 / us, "laneconv_layer_us": lc_us,
+                        "laneconv_hbm_frac": byts / (lc_us * 1e-6) / (PEAK_HBM_GBPS * 1e9),
+                        "laneconv_mfma_frac": flops / (lc_us * 1e-6) / (PEAK_TFLOPS[mma] * 1e12)}
+    except Exception as e:      # noqa: BLE001 -- auxiliary figure
+        out["error"] = repr(e)[:300]
+    finally:
+        ops.set_mma(prev)
+    return out
+
+
 def extra_timings(mods, scenes, dev):
     """The reference-facing calls on the same batch (not part of `value`): the drop-in ``Net.forward(data)`` under
     no_grad (host collate of the dict-of-lists batch included) and one training step (forward + loss + backward +
@@ -455,7 +496,7 @@ def main():
                     help="matrix-core mode (default: LGCN_MMA or f16x2 = fp32-grade 2-way fp16 split)")
     ap.add_argument("--laneconv", default=None, choices=["fused", "tiled"],
                     help="force one LaneConv implementation (default: fused with several forwards in flight, tiled for one)")
-    ap.add_argument("--other-modes", default="f32,bf16x3",
+    ap.add_argument("--other-modes", default="f32,bf16x3,bf16",
                     help="arithmetic modes reported next to the headline one in `modes` (comma list, '' = none)")
     ap.add_argument("--no-extras", action="store_true", help="skip the drop-in Net.forward / training-step timings")
     args = ap.parse_args()
@@ -529,6 +570,7 @@ def main():
         ops.set_mma(mma)
         if not args.no_extras:
             extras = extra_timings(mods, scenes, dev)
+            extras["config2_mapnet_s1"] = config2_mapnet_s1(mods, dev)
 
     if rank == 0:
         sum_e = sum(fb.n_edges)

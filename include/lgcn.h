@@ -506,6 +506,26 @@ int lgcn_att_pairs_ws(const float *agt_ctrs, const float *ctx_ctrs,
                       float eps, int mma, int seg, float *m, void *stream);
 
 /*
+ * lgcn_att_pairs_ws with WAVE-INDEPENDENT 16-pair blocks (csrc/lgcn_pairs.hip): both weights in LDS for the whole launch,
+ * a wave takes 16 pair rows from the centre offsets to m without meeting another wave; GroupNorm / ReLU / plane split
+ * in registers (the accumulator layout of one GEMM is the operand layout of the next, thanks to a K permutation of
+ * the weights).  Same outputs as lgcn_att_pairs_ws (seg = 0 / 16) up to fp32 summation order.
+ *   wkd2, wkc0e: images of Att.dist.2's Linear weight and of ctx.0's columns 0..127 made by lgcn_pack_weight_kperm
+ *   (2 x 32 KiB in F16X2, 32 KiB in BF16).  LGCN_MMA_F16X2 and LGCN_MMA_BF16 only (others: LGCN_ESHAPE -- three bf16
+ *   planes of two weights do not fit the LDS; use lgcn_att_pairs_ws).  U and V rows are addressed with 32-bit byte
+ *   offsets: fewer than 2^23 target / context rows.
+ */
+int lgcn_pack_weight_kperm(const float *W, int ld, int mma, void *out, void *stream);
+int lgcn_att_pairs_wi(const float *agt_ctrs, const float *ctx_ctrs,
+                      const int32_t *hi, const int32_t *wi,
+                      const int32_t *n_pairs, int64_t cap,
+                      const float *wd0, const float *bd0, const float *wkd2,
+                      const float *gd, const float *btd,
+                      const float *wkc0e, const float *U, const float *V,
+                      const float *gc, const float *btc,
+                      float eps, int mma, int seg, float *m, void *stream);
+
+/*
  * Att.forward for given pairs in ONE launch per tile of target rows (lanegcn.py:691-709): query path, per-pair MLP,
  * segment sum over the target's pairs (hi is sorted: contiguous), node epilogue.  Same arithmetic as
  * lgcn_agg_mlp_pair (U) + lgcn_att_pairs + lgcn_agg_mlp (tail), but the pair rows m_p stay on the CU:

@@ -142,6 +142,8 @@ SIGNATURES = {
     "lgcn_index_cnt_words": (C.c_int64, [_L, _I]),
     "lgcn_index_build": (C.c_int, [_P, _P]),
     "lgcn_att_pairs_ws": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _I, _P, _P]),
+    "lgcn_att_pairs_wi": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _I, _P, _P]),
+    "lgcn_pack_weight_kperm": (C.c_int, [_P, _I, _I, _P, _P]),
 }
 
 _lib = None

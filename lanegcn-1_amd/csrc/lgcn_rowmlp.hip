@@ -609,7 +609,7 @@ int lgcn_agg_mlp_multi(const lgcn_agg_mlp_t *const *ps, int n, void *stream) {
         bool c = false;
         const int rc = validate_agg(*ps[i], &c);
         if (rc != LGCN_OK) return rc;
-        one = one && ps[i]->n_rows > 0 && ps[i]->mma == ps[0]->mma && ps[i]->mma != LGCN_MMA_F32 && !c && ps[i]->tile_rb == 0;
+        one = one && ps[i]->n_rows > 0 && ps[i]->mma == ps[0]->mma && ps[i]->mma != LGCN_MMA_F32 && !c && ps[i]->tile_rb == ps[0]->tile_rb;
     }
     if (one && n > 1) return agg_mlp_multi_bf(ps, n, (hipStream_t)stream);
     for (int i = 0; i < n; ++i) {

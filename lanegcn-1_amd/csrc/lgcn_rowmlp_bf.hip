@@ -793,7 +793,8 @@ int agg_mlp_multi_bf(const lgcn_agg_mlp_t *const *ps, int n, hipStream_t st) {
     // one tile height for all problems: the one picked for the largest
     int64_t big = 0;
     for (int i = 0; i < n; ++i) big = ps[i]->n_rows > big ? ps[i]->n_rows : big;
-    const int rb = pick_rb(big, fmt_of(ps[0]->mma));
+    if (ps[0]->tile_rb < 0 || ps[0]->tile_rb > 4) return LGCN_EINVAL;
+    const int rb = ps[0]->tile_rb ? ps[0]->tile_rb : pick_rb(big, fmt_of(ps[0]->mma));      // one tile height for all (the caller's, or picked)
     const int rows = 16 * rb;
     MultiArgs m{};
     m.n = n;

@@ -418,9 +418,9 @@ class Att(nn.Module):
             U, V = ops.agg_mlp_pair(u_kw, v_kw)
         # few targets with many pairs each (M2A, A2A: at least as many context rows as targets): the pair kernel
         # sums the rows of a target inside every 16-aligned group, and the tail reads one row per piece
-        seg = 16 if ops.att_pairs_impl() == "ws" and ctx.shape[0] >= T else 0
-        m = ops.att_pairs(ps, self.dist[0].weight, self.dist[0].bias, ops.packed(self.dist[2].linear.weight),
-                          _gn(self.dist[2].norm), ops.packed(c0.linear.weight, 0, 128), U, V, _gn(c0.norm),
+        seg = 16 if ops.att_pairs_impl() in ("ws", "wi") and ctx.shape[0] >= T else 0
+        m = ops.att_pairs(ps, self.dist[0].weight, self.dist[0].bias, (self.dist[2].linear.weight, 0),
+                          _gn(self.dist[2].norm), (c0.linear.weight, 0), U, V, _gn(c0.norm),
                           eps=c0.norm.eps, seg=seg)
         # ctx.1 is linear: apply it to the per-target segment sum instead of every pair
         rels = [ops.RelSpec(agts, ops.packed(self.agt.weight)),
@@ -448,20 +448,21 @@ class Att(nn.Module):
     def chain_v(self):
         return ops.packed(self.ctx[0].linear.weight, 256, 128)
 
-    def pairs_tail(self, agts: Tensor, n_ctx: int, ps: ops.PairSet, U: Tensor, V: Tensor, chain_u=None, chain_v=None):
+    def pairs_tail(self, agts: Tensor, n_ctx: int, ps: ops.PairSet, U: Tensor, V: Tensor, chain_u=None, chain_v=None,
+                   tile_rb: int = 0):
         """Pair MLP + segment sum + node epilogue for given U / V (lanegcn.py:693-709); the tail's launch can emit the
         NEXT layer's U / V from its output rows (chain_u / chain_v).  Returns out or (out, U'[, V'])."""
         T = agts.shape[0]
         lin, c0 = self.linear, self.ctx[0]
-        seg = 16 if ops.att_pairs_impl() == "ws" and n_ctx >= T else 0
-        m = ops.att_pairs(ps, self.dist[0].weight, self.dist[0].bias, ops.packed(self.dist[2].linear.weight),
-                          _gn(self.dist[2].norm), ops.packed(c0.linear.weight, 0, 128), U, V, _gn(c0.norm),
+        seg = 16 if ops.att_pairs_impl() in ("ws", "wi") and n_ctx >= T else 0
+        m = ops.att_pairs(ps, self.dist[0].weight, self.dist[0].bias, (self.dist[2].linear.weight, 0),
+                          _gn(self.dist[2].norm), (c0.linear.weight, 0), U, V, _gn(c0.norm),
                           eps=c0.norm.eps, seg=seg)
         rels = [ops.RelSpec(agts, ops.packed(self.agt.weight)),
                 ops.RelSpec(m, ops.packed(self.ctx[1].weight), L.REL_RANGE16 if seg else L.REL_RANGE)]
         return ops.agg_mlp(T, rels, _FULL, rowptr=ps.rowptr, gn1=_gn(self.norm),
                            wp2=ops.packed(lin.linear.weight), gn2=_gn(lin.norm), res=agts, eps=self.norm.eps,
-                           tag="att_post", chain_u=chain_u, chain_v=chain_v)
+                           tag="att_post", chain_u=chain_u, chain_v=chain_v, tile_rb=tile_rb)
 
 
 def att_block(atts, agts: Optional[Tensor], ctx: Tensor, ps: ops.PairSet, head: Optional[dict] = None, uv=None,
@@ -478,12 +479,15 @@ def att_block(atts, agts: Optional[Tensor], ctx: Tensor, ps: ops.PairSet, head: 
     Returns (out, uv_next) -- uv_next is None without next_att."""
     n = len(atts)
     Vs = [None] * n
+    rows_t = head["n_rows"] if head is not None else agts.shape[0]
+    rb = _att_rb(rows_t)
     if uv is not None:
         U, Vs[0] = uv
     else:
         first = dict(head, chain_u=atts[0].chain_u()) if head is not None else atts[0].u_kw(agts)
         probs = [first] + [atts[i].v_kw(ctx) for i in range(1 if ctx_is_agts else n)]
-        res = ops.agg_mlp_multi(probs, tag="att_head")
+        rb_head = _att_rb(max(q["n_rows"] for q in probs))
+        res = ops.agg_mlp_multi([dict(q, tile_rb=rb_head) for q in probs], tag="att_head")
         if head is not None:
             agts, U = res[0]
         else:
@@ -500,7 +504,7 @@ def att_block(atts, agts: Optional[Tensor], ctx: Tensor, ps: ops.PairSet, head: 
         want_v = nxt is not None and (ctx_is_agts if i + 1 < n else next_ctx_is_out)
         n_ctx = agts.shape[0] if ctx_is_agts else ctx.shape[0]
         res = att.pairs_tail(agts, n_ctx, ps, U, Vs[i], chain_u=nxt.chain_u() if nxt is not None else None,
-                             chain_v=nxt.chain_v() if want_v else None)
+                             chain_v=nxt.chain_v() if want_v else None, tile_rb=rb)
         if nxt is None:
             agts = res
         elif i + 1 < n:
@@ -510,6 +514,16 @@ def att_block(atts, agts: Optional[Tensor], ctx: Tensor, ps: ops.PairSet, head: 
         else:
             agts, uv_next = res[0], (res[1], res[2] if want_v else None)
     return agts, uv_next
+
+
+def _att_rb(n_rows: int) -> int:
+    """Tile height (16-row blocks) of a fusion block's row-block launches; 0 = the library's pick.  These launches are
+    chains of up to five 128 x 128 passes whose weights every workgroup streams from L2: with enough rows to give
+    every CU a tile anyway, taller tiles halve the weight bytes a CU pulls."""
+    rb = int(os.environ.get("LGCN_ATT_RB", "-1"))
+    if rb >= 0:
+        return rb
+    return 0
 
 
 def _fold_ok(ctx: Tensor) -> bool:

@@ -992,31 +992,66 @@ def mapnet_input(ctrs, feats, wa1, ba1, wpa2, gn_a, ws1, bs1, wps2, gn_s, eps=EP
 
 # Per-pair MLP of Att: "ws" (default in the 16-bit-plane modes) = lgcn_att_pairs_ws, both weights in registers;
 # "stream" = lgcn_att_pairs, weight fragments streamed per 32-pair tile (the only one in f32).
-_att_pairs_impl = os.environ.get("LGCN_ATT_PAIRS", "ws")
+# "wi" = lgcn_att_pairs_wi, wave-independent 16-pair blocks with both weights in LDS (f16x2 / bf16; the default there).
+_att_pairs_impl = os.environ.get("LGCN_ATT_PAIRS", "wi")
 
 
 def set_att_pairs_impl(name: str):
     global _att_pairs_impl
-    if name not in ("ws", "stream"):
-        raise L.LgcnError("att pairs impl must be 'ws' or 'stream'")
+    if name not in ("wi", "ws", "stream"):
+        raise L.LgcnError("att pairs impl must be 'wi', 'ws' or 'stream'")
     _att_pairs_impl = name
 
 
 def att_pairs_impl() -> str:
-    return "stream" if _mma == L.MMA_F32 else _att_pairs_impl
+    """The pair-MLP kernel of the current matrix mode: f32 has only "stream"; "wi" needs both weights in LDS (two or one
+    16-bit plane: f16x2 / bf16), bf16x3 falls back to "ws"."""
+    if _mma == L.MMA_F32:
+        return "stream"
+    if _att_pairs_impl == "wi" and _mma not in (L.MMA_F16X2, L.MMA_BF16):
+        return "ws"
+    return _att_pairs_impl
+
+
+def packed_kperm(weight: torch.Tensor, col0: int = 0) -> torch.Tensor:
+    """K-permuted MFMA image of weight[:, col0:col0+128] for lgcn_att_pairs_wi (lgcn_pack_weight_kperm); cached on the
+    parameter like packed() (rebuilt on first use after the parameter changed)."""
+    lib = L.load()
+    mma = _mma
+
+    def make():
+        w = _dev(weight.detach(), torch.float32, "weight")
+        out = torch.empty(lib.lgcn_packed_bytes(C_FEAT, mma) // 4, dtype=torch.float32, device=w.device)
+        L.check(lib.lgcn_pack_weight_kperm(C.c_void_p(w[:, col0:].data_ptr()), w.stride(0), mma, _ptr(out), _stream()),
+                "lgcn_pack_weight_kperm")
+        return out
+
+    return _cached(weight, ("packK", col0, mma), make)
 
 
 def att_pairs(ps: PairSet, wd0, bd0, wpd2, gn_d, wpc0e, U, V, gn_c, m=None, eps=EPS, seg=0, tag="att_pairs"):
-    """m [cap,128] of lgcn_att_pairs / lgcn_att_pairs_ws.  seg = 16 (ws only): per-target sums of 16-aligned
-    pieces at each piece's first row; hand m to agg_mlp as a REL_RANGE16 relation."""
+    """m [cap,128] of lgcn_att_pairs / lgcn_att_pairs_ws / lgcn_att_pairs_wi.  seg = 16 (ws / wi): per-target sums of
+    16-aligned pieces at each piece's first row; hand m to agg_mlp as a REL_RANGE16 relation.
+    wpd2 / wpc0e: (weight parameter, first column) -- packed here in the layout of the kernel in use -- or, for the ws /
+    stream kernels, an image already made by packed()."""
     lib = L.load()
+    impl = att_pairs_impl()
+    if isinstance(wpd2, tuple) != isinstance(wpc0e, tuple):
+        raise L.LgcnError("att_pairs: both weights as (parameter, column) or both packed")
+    if isinstance(wpd2, tuple):
+        pk = packed_kperm if impl == "wi" else (lambda w, c: packed(w, c, C_FEAT))
+        wpd2, wpc0e = pk(*wpd2), pk(*wpc0e)
+    elif impl == "wi":
+        impl = "ws"          # images made by packed(): the kernels that read that layout
     if m is None:
         m = torch.empty((max(ps.cap, 1), C_FEAT), dtype=torch.float32, device=U.device)
     args = (_ptr(ps.agt_ctrs), _ptr(ps.ctx_ctrs), _ptr(ps.hi), _ptr(ps.wi), _ptr(ps.n_pairs),
             ps.cap, _ptr(wd0), _ptr(bd0), _ptr(wpd2), _ptr(gn_d[0]), _ptr(gn_d[1]), _ptr(wpc0e),
             _ptr(U), _ptr(V), _ptr(gn_c[0]), _ptr(gn_c[1]), eps, _mma)
     with _Timed(tag):
-        if att_pairs_impl() == "ws":
+        if impl == "wi":
+            rc = lib.lgcn_att_pairs_wi(*args, seg, _ptr(m), _stream())
+        elif impl == "ws":
             rc = lib.lgcn_att_pairs_ws(*args, seg, _ptr(m), _stream())
         elif seg != 0:
             raise L.LgcnError("att_pairs: seg needs the weight-stationary kernel (16-bit-plane modes)")

@@ -946,9 +946,10 @@ def test_att_fused_launch_vs_reference_captures(gcase, golden, hip, mma_mode):
 
 
 def test_att_pairs_weight_stationary_and_pieces(gcase, golden, hip, mma_mode):
-    """lgcn_att_pairs_ws (weights in registers, 64-pair tiles): (1) seg = 0 writes the same pair rows as the
-    streaming kernel; (2) seg = 16 writes exactly the per-target sums of the 16-aligned pieces, at the piece's first
-    row, and touches no other row; (3) the whole hot path with either pair kernel meets the reference captures."""
+    """lgcn_att_pairs_ws (weights in registers, 64-pair tiles) and lgcn_att_pairs_wi (weights in LDS, wave-independent
+    16-pair blocks): (1) seg = 0 writes the same pair rows as the streaming kernel; (2) seg = 16 writes exactly the
+    per-target sums of the 16-aligned pieces, at the piece's first row, and touches no other row; (3) the whole hot path
+    with every pair kernel meets the reference captures."""
     M, ops = hip
     if mma_mode == "f32":
         pytest.skip("split-precision kernel")
@@ -956,14 +957,14 @@ def test_att_pairs_weight_stationary_and_pieces(gcase, golden, hip, mma_mode):
     actors = torch.from_numpy(golden["actors_in"])
     # (3) both implementations end to end
     try:
-        for impl in ("stream", "ws"):
+        for impl in ("stream", "ws", "wi"):
             ops.set_att_pairs_impl(impl)
             out, _ = run_hot_path(M, mods, scenes, actors)
             for k in ("a2m", "m2m", "m2a", "a2a"):
                 err = float(np.abs(out[k] - golden[k]).max())
                 assert err <= FTOL, (impl, k, err)
     finally:
-        ops.set_att_pairs_impl("ws")
+        ops.set_att_pairs_impl("wi")
     # (1), (2) on the A2A pair set of the fixture (ragged: 5 scenes, several pairs per target)
     att = mods["a2a"].att[0]
     ctrs = [s["ctrs"].cuda() for s in scenes]
@@ -980,26 +981,30 @@ def test_att_pairs_weight_stationary_and_pieces(gcase, golden, hip, mma_mode):
         U = ops.agg_mlp(n, [ops.RelSpec(x, ops.packed(att.query.linear.weight))], M.L.F_GN1 | M.L.F_RELU1 | M.L.F_GEMM2,
                         gn1=M._gn(att.query.norm), wp2=ops.packed(c0.linear.weight, 128, 128))
         V = ops.agg_mlp(n, [ops.RelSpec(x, ops.packed(c0.linear.weight, 256, 128))], 0)
-        args = (ps, att.dist[0].weight, att.dist[0].bias, ops.packed(att.dist[2].linear.weight), M._gn(att.dist[2].norm),
-                ops.packed(c0.linear.weight, 0, 128), U, V, M._gn(c0.norm))
+        args = (ps, att.dist[0].weight, att.dist[0].bias, (att.dist[2].linear.weight, 0), M._gn(att.dist[2].norm),
+                (c0.linear.weight, 0), U, V, M._gn(c0.norm))
         ops.set_att_pairs_impl("stream")
         try:
             m_ref = ops.att_pairs(*args)[:P].cpu().numpy()
+            hi = ps.hi[:P].cpu().numpy()
+            first = np.ones(P, bool)
+            first[1:] = (hi[1:] != hi[:-1]) | (np.arange(1, P) % 16 == 0)
+            starts = np.flatnonzero(first)
+            untouched = np.ones(ps.cap, bool)
+            untouched[starts] = False
+            for impl in ("ws", "wi"):
+                ops.set_att_pairs_impl(impl)
+                if ops.att_pairs_impl() != impl:
+                    continue                      # wi: two- / one-plane modes only
+                m_k = ops.att_pairs(*args)[:P].cpu().numpy()
+                assert float(np.abs(m_k - m_ref).max()) <= 2e-5 * max(1.0, float(np.abs(m_ref).max())), impl
+                canary = torch.full((ps.cap, 128), 7777.0, device="cuda")
+                m_seg = ops.att_pairs(*args, m=canary, seg=16).cpu().numpy()
+                want = np.add.reduceat(m_k.astype(np.float64), starts, axis=0)
+                assert float(np.abs(m_seg[starts] - want).max()) <= 1e-4 * max(1.0, float(np.abs(want).max())), impl
+                assert (m_seg[untouched] == 7777.0).all(), impl
         finally:
-            ops.set_att_pairs_impl("ws")
-        m_ws = ops.att_pairs(*args)[:P].cpu().numpy()
-        assert float(np.abs(m_ws - m_ref).max()) <= 2e-5 * max(1.0, float(np.abs(m_ref).max()))
-        canary = torch.full((ps.cap, 128), 7777.0, device="cuda")
-        m_seg = ops.att_pairs(*args, m=canary, seg=16).cpu().numpy()
-        hi = ps.hi[:P].cpu().numpy()
-        first = np.ones(P, bool)
-        first[1:] = (hi[1:] != hi[:-1]) | (np.arange(1, P) % 16 == 0)
-        starts = np.flatnonzero(first)
-        want = np.add.reduceat(m_ws.astype(np.float64), starts, axis=0)
-        assert float(np.abs(m_seg[starts] - want).max()) <= 1e-4 * max(1.0, float(np.abs(want).max()))
-        untouched = np.ones(ps.cap, bool)
-        untouched[starts] = False
-        assert (m_seg[untouched] == 7777.0).all()
+            ops.set_att_pairs_impl("wi")
 
 
 def test_net_forward_graph_cache(golden, ref_state_names, hip):
