@@ -526,6 +526,25 @@ int lgcn_att_pairs_wi(const float *agt_ctrs, const float *ctx_ctrs,
                       float eps, int mma, int seg, float *m, void *stream);
 
 /*
+ * PredLoss (reference lanegcn.py:740-807), forward and backward, one launch each.
+ *   cls [A, M], reg [A, M, T, 2], gt [A, T, 2] fp32; has [A, T] bytes (torch.bool); M <= 8, T <= 64.
+ * Per actor: last = argmax_t(has[t] + 0.1 t / T), kept iff that maximum > 1.0; dist_j = |reg[j, last] - gt[last]|;
+ * (min_dist, min_idx) = min_j; max-margin term over the modes j with min_dist < cls_th and dist_j - min_dist >
+ * cls_ignore and cls[min_idx] - cls[j] < mgn; SmoothL1 (beta 1) of reg[min_idx, t] - gt[t] over the observed steps.
+ *   sums[0] = cls_coef * sum (mgn - margin), sums[1] = reg_coef * sum SmoothL1; counts[0] = num_cls, counts[1] = num_reg
+ *   (the reference's loss_out entries; Loss.forward divides by the counts, :818-820);
+ *   sel [A]: min_idx | (hinge bits << 8), -1 for a dropped actor: input of the backward.
+ * Index / mask decisions use the same fp32 operations as ATen; sums in a fixed order (no atomics).
+ * Backward: dcls [A, M], dreg [A, M, T, 2] (every element written) for upstream gradients g_cls, g_reg (device scalars).
+ */
+int lgcn_pred_loss_fwd(const float *cls, const float *reg, const float *gt, const unsigned char *has, int64_t n_act,
+                       int n_mod, int n_t, float cls_th, float cls_ignore, float mgn, float cls_coef, float reg_coef,
+                       float *sums, int32_t *counts, int32_t *sel, void *stream);
+int lgcn_pred_loss_bwd(const float *cls, const float *reg, const float *gt, const unsigned char *has, int64_t n_act,
+                       int n_mod, int n_t, float cls_coef, float reg_coef, const int32_t *sel, const float *g_cls,
+                       const float *g_reg, float *dcls, float *dreg, void *stream);
+
+/*
  * Att.forward for given pairs in ONE launch per tile of target rows (lanegcn.py:691-709): query path, per-pair MLP,
  * segment sum over the target's pairs (hi is sorted: contiguous), node epilogue.  Same arithmetic as
  * lgcn_agg_mlp_pair (U) + lgcn_att_pairs + lgcn_agg_mlp (tail), but the pair rows m_p stay on the CU:

@@ -144,6 +144,8 @@ SIGNATURES = {
     "lgcn_att_pairs_ws": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _I, _P, _P]),
     "lgcn_att_pairs_wi": (C.c_int, [_P, _P, _P, _P, _P, _L] + [_P] * 10 + [_F, _I, _I, _P, _P]),
     "lgcn_pack_weight_kperm": (C.c_int, [_P, _I, _I, _P, _P]),
+    "lgcn_pred_loss_fwd": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _F, _F, _F, _F, _F, _P, _P, _P, _P]),
+    "lgcn_pred_loss_bwd": (C.c_int, [_P, _P, _P, _P, _L, _I, _I, _F, _F, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

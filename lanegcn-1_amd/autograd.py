@@ -265,3 +265,24 @@ def linear_gn(x, weight, gn=None, relu=False, res=None, col0=0):
 def gn_act(x, gn=None, relu=False, res=None):
     gw, gb = (gn.weight, gn.bias) if gn is not None else (None, None)
     return GNActFn.apply(x, gw, gb, res, relu, gn.eps if gn is not None else ops.EPS)
+
+
+class PredLossFn(torch.autograd.Function):
+    """PredLoss's two sums (reference lanegcn.py:740-807) in one launch, gradients in one more (csrc/lgcn_loss.hip).
+    Returns (cls_loss, reg_loss, counts [2] int32 on the device: num_cls, num_reg)."""
+
+    @staticmethod
+    def forward(ctx, cls, reg, gt, has, cfg):
+        cls, reg = cls.contiguous(), reg.contiguous()
+        sums, counts, sel = ops.pred_loss_fwd(cls, reg, gt, has, cfg)
+        ctx.save_for_backward(cls, reg, gt, has, sel)
+        ctx.cfg = cfg
+        ctx.mark_non_differentiable(counts)
+        return sums[0], sums[1], counts
+
+    @staticmethod
+    def backward(ctx, g_cls, g_reg, _):
+        cls, reg, gt, has, sel = ctx.saved_tensors
+        z = lambda g: torch.zeros(1, dtype=torch.float32, device=cls.device) if g is None else g.reshape(1).float().contiguous()
+        dcls, dreg = ops.pred_loss_bwd(cls, reg, gt, has, ctx.cfg, sel, z(g_cls), z(g_reg))
+        return dcls, dreg, None, None, None

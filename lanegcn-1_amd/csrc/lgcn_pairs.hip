@@ -33,6 +33,11 @@
 #include "lgcn_tile.hpp"
 #include "lgcn_mma_bf.hpp"
 
+// fused multiply-adds allowed in this file (the library is built with -ffp-contract=off for the bit-exact pair search
+// of lgcn_index.hip; nothing here is compared bit for bit with ATen): fewer VALU instructions per element, and every
+// contraction only removes a rounding
+#pragma clang fp contract(fast)
+
 namespace lgcn {
 
 // channel held by (K-step s, lane group g, slot j) of an operand fragment / by accumulator (cb = 2 s + (j >> 2), i = j & 3)
@@ -93,7 +98,16 @@ __global__ __launch_bounds__(1024) void k_att_pairs_wi(const PairParams p) {
     };
     int hi_c, wi_c;
     fetch_idx(blk, hi_c, wi_c);
+    auto fetch_d = [&](int h, int w, float &x, float &y) {      // centre offset of a pair (0 for a dead row)
+        x = y = 0.f;
+        if (h >= 0) {
+            const float2 a = reinterpret_cast<const float2 *>(p.agt_ctrs)[h];
+            const float2 c = reinterpret_cast<const float2 *>(p.ctx_ctrs)[w];
+            x = a.x - c.x; y = a.y - c.y;
+        }
+    };
 
+    float dx, dy;
     {   // weights -> LDS (the packed images are already in fragment order), parameters -> LDS
         const uint4 *B1 = reinterpret_cast<const uint4 *>(p.wpd2), *B2 = reinterpret_cast<const uint4 *>(p.wpc0e);
         uint4 t[2 * NP * WFR / 1024];
@@ -102,6 +116,7 @@ __global__ __launch_bounds__(1024) void k_att_pairs_wi(const PairParams p) {
             const int e = tid + 1024 * i;
             t[i] = e < NP * WFR ? B1[e] : B2[e - NP * WFR];
         }
+        fetch_d(hi_c, wi_c, dx, dy);      // the first block's centres: requested behind the weight loads, land under the copy
         if (tid < kC) {
             s_par[tid] = p.wd0[2 * tid];
             s_par[kC + tid] = p.wd0[2 * tid + 1];
@@ -157,9 +172,16 @@ __global__ __launch_bounds__(1024) void k_att_pairs_wi(const PairParams p) {
             const uint32_t a = Fmt<F>::pack(v[0], v[1]), b = Fmt<F>::pack(v[2], v[3]);
             if (cb & 1) { x[pl][cb >> 1].z = a; x[pl][cb >> 1].w = b; }
             else { x[pl][cb >> 1].x = a; x[pl][cb >> 1].y = b; }
-            if (pl + 1 < NP) {
-                const f32x2 ra = Fmt<F>::unpack(a), rb = Fmt<F>::unpack(b);
-                v[0] -= ra.x; v[1] -= ra.y; v[2] -= rb.x; v[3] -= rb.y;
+            if (pl + 1 < NP) {      // the residual x - plane, exact in fp32
+                if (F == 1) {       // v_fma_mix_f32 reads the fp16 half directly: one instruction instead of convert + subtract
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(v[0]) : "v"(a));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v[1]) : "v"(a));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel_hi:[1,0,0]" : "+v"(v[2]) : "v"(b));
+                    asm("v_fma_mix_f32 %0, %1, -1.0, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(v[3]) : "v"(b));
+                } else {
+                    const f32x2 ra = Fmt<F>::unpack(a), rb = Fmt<F>::unpack(b);
+                    v[0] -= ra.x; v[1] -= ra.y; v[2] -= rb.x; v[3] -= rb.y;
+                }
             }
         }
     };
@@ -167,19 +189,22 @@ __global__ __launch_bounds__(1024) void k_att_pairs_wi(const PairParams p) {
     const int a16 = (lane ^ 16) << 2, a32 = (lane ^ 32) << 2;
     auto xlane = [](float v, int addr) { return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, v))); };
     // GroupNorm(1, 128) of the row held by lanes r, r + 16, r + 32, r + 48 (32 channels each): two-pass, like row_gn
-    auto row_stats = [&](const f32x4 (&a)[8], float &mean, float &rstd) {
+    // On return a[] holds the CENTRED values x - mean (what the normalisation needs next).
+    auto row_stats = [&](f32x4 (&a)[8], float &rstd) {
         float s = 0.f;
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) s += (a[cb][0] + a[cb][1]) + (a[cb][2] + a[cb][3]);
         s += xlane(s, a16);
         s += xlane(s, a32);
-        mean = s * (1.0f / kC);
-        float q = 0.f;
+        const float mean = s * (1.0f / kC);
+        float q0 = 0.f, q1 = 0.f;
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
-            const float d0 = a[cb][0] - mean, d1 = a[cb][1] - mean, d2 = a[cb][2] - mean, d3 = a[cb][3] - mean;
-            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            a[cb] = a[cb] - f32x4{mean, mean, mean, mean};
+            q0 = fmaf(a[cb][0], a[cb][0], q0); q1 = fmaf(a[cb][1], a[cb][1], q1);
+            q0 = fmaf(a[cb][2], a[cb][2], q0); q1 = fmaf(a[cb][3], a[cb][3], q1);
         }
+        float q = q0 + q1;
         q += xlane(q, a16);
         q += xlane(q, a32);
         rstd = 1.0f / sqrtf(q * (1.0f / kC) + p.eps);
@@ -190,22 +215,16 @@ __global__ __launch_bounds__(1024) void k_att_pairs_wi(const PairParams p) {
         const int go = 4 * g, ro = r;
         int hi_n, wi_n;
         fetch_idx(blk + stride, hi_n, wi_n);                 // next block's indices: a block ahead
-        float dx = 0.f, dy = 0.f;
-        if (live) {
-            const float2 a = reinterpret_cast<const float2 *>(p.agt_ctrs)[hi_c];
-            const float2 c = reinterpret_cast<const float2 *>(p.ctx_ctrs)[wi_c];
-            dx = a.x - c.x; dy = a.y - c.y;
-        }
         // ---- e0 = ReLU(W_d0 d + b_d0) for this lane's 32 channels -> operand planes
         uint4 x[NP][4];
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) {
             const float4 wx = l_wx[4 * cb], wy = l_wy[4 * cb], bb = l_b0[4 * cb];
             f32x4 h;
-            h[0] = relu_nan(dx * wx.x + dy * wy.x + bb.x);
-            h[1] = relu_nan(dx * wx.y + dy * wy.y + bb.y);
-            h[2] = relu_nan(dx * wx.z + dy * wy.z + bb.z);
-            h[3] = relu_nan(dx * wx.w + dy * wy.w + bb.w);
+            h[0] = relu_nan(fmaf(dy, wy.x, fmaf(dx, wx.x, bb.x)));
+            h[1] = relu_nan(fmaf(dy, wy.y, fmaf(dx, wx.y, bb.y)));
+            h[2] = relu_nan(fmaf(dy, wy.z, fmaf(dx, wx.z, bb.z)));
+            h[3] = relu_nan(fmaf(dy, wy.w, fmaf(dx, wx.w, bb.w)));
             to_planes(x, cb, h);
         }
         // ---- e1 = W_d2 e0
@@ -213,20 +232,21 @@ __global__ __launch_bounds__(1024) void k_att_pairs_wi(const PairParams p) {
 #pragma unroll
         for (int cb = 0; cb < 8; ++cb) acc[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm(w1, x, acc, [](int) {});
+        fetch_d(hi_n, wi_n, dx, dy);                         // next block's centres (its indices have landed): under GN1 / the second GEMM
         // ---- e = ReLU(GN_d(e1)) -> operand planes (registers only); an accumulator block that has been normalised is
         // dead: U[h]'s block is requested into it (the second GEMM's accumulators start from U[h])
         const float *up = p.U + (unsigned)((live ? hi_c : 0) * kC + go);      // scalar base + 32-bit lane offset (rows < 2^24)
         {
-            float mean, rstd;
-            row_stats(acc, mean, rstd);
+            float rstd;
+            row_stats(acc, rstd);
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
                 const float4 gg = l_gd[4 * cb], bb = l_bd[4 * cb];
                 f32x4 v;
-                v[0] = relu_nan((acc[cb][0] - mean) * rstd * gg.x + bb.x);
-                v[1] = relu_nan((acc[cb][1] - mean) * rstd * gg.y + bb.y);
-                v[2] = relu_nan((acc[cb][2] - mean) * rstd * gg.z + bb.z);
-                v[3] = relu_nan((acc[cb][3] - mean) * rstd * gg.w + bb.w);
+                v[0] = relu_nan(fmaf(acc[cb][0] * rstd, gg.x, bb.x));
+                v[1] = relu_nan(fmaf(acc[cb][1] * rstd, gg.y, bb.y));
+                v[2] = relu_nan(fmaf(acc[cb][2] * rstd, gg.z, bb.z));
+                v[3] = relu_nan(fmaf(acc[cb][3] * rstd, gg.w, bb.w));
                 to_planes(x, cb, v);
                 acc[cb] = *reinterpret_cast<const f32x4 *>(up + 16 * cb);
             }
@@ -242,15 +262,15 @@ __global__ __launch_bounds__(1024) void k_att_pairs_wi(const PairParams p) {
         for (int cb = 0; cb < 8; ++cb) acc[cb] = acc[cb] + vv[cb];
         // ---- m = ReLU(GN_c(t))
         {
-            float mean, rstd;
-            row_stats(acc, mean, rstd);
+            float rstd;
+            row_stats(acc, rstd);
 #pragma unroll
             for (int cb = 0; cb < 8; ++cb) {
                 const float4 gg = l_gc[4 * cb], bb = l_bc[4 * cb];
-                acc[cb][0] = relu_nan((acc[cb][0] - mean) * rstd * gg.x + bb.x);
-                acc[cb][1] = relu_nan((acc[cb][1] - mean) * rstd * gg.y + bb.y);
-                acc[cb][2] = relu_nan((acc[cb][2] - mean) * rstd * gg.z + bb.z);
-                acc[cb][3] = relu_nan((acc[cb][3] - mean) * rstd * gg.w + bb.w);
+                acc[cb][0] = relu_nan(fmaf(acc[cb][0] * rstd, gg.x, bb.x));
+                acc[cb][1] = relu_nan(fmaf(acc[cb][1] * rstd, gg.y, bb.y));
+                acc[cb][2] = relu_nan(fmaf(acc[cb][2] * rstd, gg.z, bb.z));
+                acc[cb][3] = relu_nan(fmaf(acc[cb][3] * rstd, gg.w, bb.w));
             }
         }
         float *mp = p.m + (int64_t)blk * (16 * kC) + (unsigned)(ro * kC + go);      // scalar base + lane offset
@@ -271,10 +291,10 @@ __global__ __launch_bounds__(1024) void k_att_pairs_wi(const PairParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     float y = acc[cb][i];
-                    y = dpp_mov<0x101>(y) * m1 + y;
-                    y = dpp_mov<0x102>(y) * m2 + y;
-                    y = dpp_mov<0x104>(y) * m4 + y;
-                    y = dpp_mov<0x108>(y) * m8 + y;
+                    y = fmaf(dpp_mov<0x101>(y), m1, y);
+                    y = fmaf(dpp_mov<0x102>(y), m2, y);
+                    y = fmaf(dpp_mov<0x104>(y), m4, y);
+                    y = fmaf(dpp_mov<0x108>(y), m8, y);
                     acc[cb][i] = y;
                     if (i == 3) __builtin_amdgcn_sched_barrier(0);      // one channel block at a time (register budget)
                 }

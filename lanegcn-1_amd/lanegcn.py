@@ -1011,6 +1011,8 @@ def _tree_cpu(x):
 class PredLoss(nn.Module):
     """Max-margin mode classification + SmoothL1 regression of the closest mode (reference lanegcn.py:740-807)."""
 
+    impl = os.environ.get("LGCN_PREDLOSS", "hip")      # "stock": the ATen composition below
+
     def __init__(self, config):
         super().__init__()
         self.config = config
@@ -1020,6 +1022,13 @@ class PredLoss(nn.Module):
         cfg = self.config
         cls, reg = torch.cat(list(out["cls"]), 0), torch.cat(list(out["reg"]), 0)
         gt_preds, has_preds = torch.cat(list(gt_preds), 0), torch.cat(list(has_preds), 0)
+        if (PredLoss.impl == "hip" and cls.is_cuda and cls.dtype == torch.float32 and reg.dim() == 4 and cls.shape[1] <= 8
+                and reg.shape[2] <= 64 and has_preds.dtype == torch.bool):
+            # one launch forward, one backward (csrc/lgcn_loss.hip); the counts come back in ONE 8-byte read -- the
+            # reference reads them with two .item() calls (:801, :807)
+            c_loss, r_loss, counts = A.PredLossFn.apply(cls, reg, gt_preds.float().contiguous(), has_preds.contiguous(), cfg)
+            n_cls, n_reg = counts.tolist()
+            return {"cls_loss": c_loss, "num_cls": n_cls, "reg_loss": r_loss, "num_reg": n_reg}
         zero = 0.0 * (cls.sum() + reg.sum())
         loss_out = {"cls_loss": zero.clone(), "num_cls": 0, "reg_loss": zero.clone(), "num_reg": 0}
         num_mods, num_preds = cfg["num_mods"], cfg["num_preds"]

@@ -1092,6 +1092,30 @@ def att_fused(agts, ps: PairSet, V, wq, gn_q, wc0q, wd0, bd0, wd2, gn_d, wc0e, g
     return out
 
 
+def pred_loss_fwd(cls, reg, gt, has, cfg):
+    """lgcn_pred_loss_fwd: (sums [2] fp32 = cls_loss, reg_loss; counts [2] int32 = num_cls, num_reg; sel [A] int32)."""
+    lib = L.load()
+    A, M = cls.shape
+    T = reg.shape[2]
+    dev = cls.device
+    sums = torch.empty(2, dtype=torch.float32, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    sel = torch.empty(max(A, 1), dtype=torch.int32, device=dev)
+    L.check(lib.lgcn_pred_loss_fwd(_ptr(cls), _ptr(reg), _ptr(gt), _ptr(has), A, M, T, cfg["cls_th"], cfg["cls_ignore"], cfg["mgn"],
+                                   cfg["cls_coef"], cfg["reg_coef"], _ptr(sums), _ptr(counts), _ptr(sel), _stream()), "lgcn_pred_loss_fwd")
+    return sums, counts, sel
+
+
+def pred_loss_bwd(cls, reg, gt, has, cfg, sel, g_cls, g_reg):
+    lib = L.load()
+    A, M = cls.shape
+    T = reg.shape[2]
+    dcls, dreg = torch.empty_like(cls), torch.empty_like(reg)
+    L.check(lib.lgcn_pred_loss_bwd(_ptr(cls), _ptr(reg), _ptr(gt), _ptr(has), A, M, T, cfg["cls_coef"], cfg["reg_coef"], _ptr(sel),
+                                   _ptr(g_cls), _ptr(g_reg), _ptr(dcls), _ptr(dreg), _stream()), "lgcn_pred_loss_bwd")
+    return dcls, dreg
+
+
 # ------------------------------------------------------------------ backward building blocks
 def gn_fwd(x, gn=None, res=None, relu=False, eps=EPS):
     """out = [ReLU](GroupNorm(1,128)(x) [+ res]) as a stand-alone row kernel."""

@@ -394,3 +394,39 @@ def test_gn_cl_function_gradients_vs_fp64(shape):
                 assert float((rg.grad.cpu().double() - rd.grad).abs().max()) <= 1e-6
             assert float((gg.weight.grad.cpu().double() - gd.weight.grad).abs().max()) <= 2e-5 * scale(gd.weight.grad)
             assert float((gg.bias.grad.cpu().double() - gd.bias.grad).abs().max()) <= 2e-5 * scale(gd.bias.grad)
+
+
+def test_pred_loss_hip_equals_stock_composition():
+    """PredLoss on lgcn_pred_loss_fwd / _bwd (reference lanegcn.py:740-807) against the ATen composition of the same
+    class: counts equal, sums to 1e-6 relative, gradients to 1e-6 -- with actors without any observed step, actors
+    whose only observed step is t = 0 (dropped, :769-771), ties broken by mode order, and modes inside / outside the
+    margin and ignore bands."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import lanegcn as M
+    g = torch.Generator().manual_seed(3)
+    for A in (1, 7, 333, 1600):
+        gt = torch.cumsum(torch.randn(A, 30, 2, generator=g), 1).cuda()
+        reg = (gt.unsqueeze(1).cpu() + 0.6 * torch.randn(A, 6, 30, 2, generator=g) * torch.rand(A, 6, 1, 1, generator=g) * 3).cuda()
+        reg[:, 2] = reg[:, 1]                                        # equal distances: first minimum wins
+        cls = torch.randn(A, 6, generator=g).cuda() * 0.3
+        has = (torch.rand(A, 30, generator=g) > 0.3).cuda()
+        has[::5] = False                                             # never observed
+        if A > 3:
+            has[3] = False
+            has[3, 0] = True                                         # only t = 0: dropped
+        res = {}
+        for impl in ("stock", "hip"):
+            M.PredLoss.impl = impl
+            c, r = cls.clone().requires_grad_(True), reg.clone().requires_grad_(True)
+            sizes = [A // 2, A - A // 2] if A > 1 else [A]
+            out = {"cls": list(torch.split(c, sizes)), "reg": list(torch.split(r, sizes))}
+            lo = M.Loss(M.config)(out, {"gt_preds": list(torch.split(gt, sizes)), "has_preds": list(torch.split(has, sizes))})
+            lo["loss"].backward()
+            res[impl] = (lo, c.grad.clone(), r.grad.clone())
+        M.PredLoss.impl = "hip"
+        a, b = res["stock"], res["hip"]
+        assert a[0]["num_cls"] == b[0]["num_cls"] and a[0]["num_reg"] == b[0]["num_reg"], A
+        for k in ("cls_loss", "reg_loss", "loss"):
+            assert float(b[0][k]) == pytest.approx(float(a[0][k]), rel=2e-6, abs=1e-6), (A, k)
+        assert float((a[1] - b[1]).abs().max()) <= 1e-6 * max(1.0, float(a[1].abs().max())), A
+        assert float((a[2] - b[2]).abs().max()) <= 1e-6 * max(1.0, float(a[2].abs().max())), A
