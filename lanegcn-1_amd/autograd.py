@@ -248,6 +248,21 @@ class PairAddFn(Function):
         return g, dU, dV, None
 
 
+class GatherSumFn(Function):
+    """out[n] = sum of src rows over a CSR (rowptr, col) by destination: the differentiable index_add_ of a gathered
+    tensor (reference lanercnn.py:343: out.index_add_(0, v, agt_fc(agt[u]))).  Backward = the same gather over the
+    transposed CSR (plan_t: rows = sources)."""
+
+    @staticmethod
+    def forward(ctx, src, plan, plan_t, n_rows: int):
+        ctx.plan_t, ctx.n_src = plan_t, src.shape[0]
+        return ops.gather_sum(src.contiguous(), plan.rowptr, plan.col, n_rows)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.gather_sum(g.contiguous(), ctx.plan_t.rowptr, ctx.plan_t.col, ctx.n_src), None, None, None
+
+
 # ------------------------------------------------------------------ convenience wrappers
 def row_block(srcs, weights, rels, n_rows, gn=None, relu=False, res=None, **kw):
     """Differentiable row block.  gn: nn.GroupNorm or None."""

@@ -8,8 +8,9 @@ Same class names, constructor arguments, forward signatures and state_dict names
   LanePooling    lanercnn.py:433-514  distance-gated pooling between two lane graphs: the Att pattern with a 4-d
                                       relative pose instead of the 2-d offset and without a query term
 
-Inference (no_grad) runs on the HIP kernels; LaneRoI / GlobalGraphNet also train through the LaneConv autograd
-path of lanegcn.py.  LanePooling and LaneInput do not record gradients yet (they raise instead of falling back).
+Inference (no_grad) runs on the HIP kernels; under autograd LaneRoI / GlobalGraphNet train through the LaneConv
+autograd path of lanegcn.py, LanePooling and LaneInput through the row-block / pair / gather Functions of autograd.py
+(the same composition as Att.run_train): every 128-d contraction of the backward is a HIP launch as well.
 """
 from math import gcd
 from typing import Dict, List
@@ -20,14 +21,10 @@ from torch import Tensor, nn
 from torch.nn import functional as F
 
 from . import _lib as L
+from . import autograd as A
 from . import ops
 from .lanegcn import _fuse_modules, _gn, build_pairs, lane_conv, lane_conv_train, lane_plan, lane_plan_t
 from .layers import Linear
-
-
-def _no_grad_only(name, *tensors_and_params):
-    if ops.wants_grad(*tensors_and_params):
-        raise L.LgcnError("%s: the HIP path of this module is forward-only (use torch.no_grad())" % name)
 
 
 def _need_cuda(*ts):
@@ -51,7 +48,7 @@ class LaneInput(nn.Module):
         map_feats = torch.cat(graph["feats"], 0)            # [nodes, 8]
         agt_feats = torch.cat(graph["agent_feat"], 0)       # [agts, 80]
         _need_cuda(map_feats, agt_feats)
-        _no_grad_only("LaneInput", map_feats, agt_feats, *ops.module_params(self))
+        train = ops.wants_grad(map_feats, agt_feats, *ops.module_params(self))
         n = map_feats.shape[0]
         # the two Linears have K = 8 / 80 (not 128-d contractions): stock ops; agt_fc commutes with the gather
         base = self.map_fc(map_feats)
@@ -60,8 +57,14 @@ class LaneInput(nn.Module):
         if u.numel() > 0:
             # one relation: key(n, 0) = n, i.e. a plain CSR by node (sized for the larger index space: the builder
             # bounds-checks sources and destinations against the same count)
-            plan = ops.csr_build([v], [u], max(n, agt.shape[0]))
-            base = base + ops.gather_sum(agt, plan.rowptr, plan.col, n)
+            rows = max(n, agt.shape[0])
+            plan = ops.csr_build([v], [u], rows)
+            if train:      # the gather's transpose = the same gather over the CSR by source
+                base = base + A.GatherSumFn.apply(agt, plan, ops.csr_build([u], [v], rows), n)
+            else:
+                base = base + ops.gather_sum(agt, plan.rowptr, plan.col, n)
+        if train:
+            return A.gn_act(base.contiguous(), gn=self.bn, relu=True)
         return ops.gn_fwd(base.contiguous(), _gn(self.bn), relu=True, eps=self.bn.eps)
 
 
@@ -121,10 +124,11 @@ class LanePooling(nn.Module):
     def forward(self, context_feat: Tensor, context_graph: Dict, target_feat: Tensor, target_graph: Dict,
                 dist_th: float = 6.0, g2r: bool = False) -> Tensor:
         _need_cuda(context_feat, target_feat)
-        _no_grad_only("LanePooling", context_feat, target_feat, *ops.module_params(self))
+        if ops.wants_grad(context_feat, target_feat, *ops.module_params(self)):
+            return self._run(context_feat, context_graph, target_feat, target_graph, dist_th, train=True)
         return ops.guarded(lambda: self._run(context_feat, context_graph, target_feat, target_graph, dist_th))
 
-    def _run(self, context_feat, context_graph, target_feat, target_graph, dist_th):
+    def _run(self, context_feat, context_graph, target_feat, target_graph, dist_th, train=False):
         c_ctrs, t_ctrs = context_graph["ctrs"], target_graph["ctrs"]
         # The reference lists the pairs context-major (hi = context row, wi = target row) and index_add_s them by
         # TARGET (:509): for one target the contributions arrive in ascending context order.  Searching with the
@@ -141,6 +145,18 @@ class LanePooling(nn.Module):
         t_pose = torch.cat(target_graph["pose"], 0)
         h = F.relu(self.relpose[0](c_pose[c_idx] - t_pose[t_idx]))                        # [P,128]; K = 4: stock op
         w0 = self.ctx[0].linear.weight                                                     # [128, 256] = [feat | pose]
+        if train:      # the differentiable composition of the same arithmetic (cf. Att.run_train)
+            m0, m1 = self.mlp[0], self.mlp[1]
+            per_ctx = A.linear_gn(context_feat, w0, col0=0)
+            per_pair = A.linear_gn(h.contiguous(), w0, col0=128)
+            no_query = torch.zeros((T, ops.C_FEAT), dtype=torch.float32, device=per_pair.device)
+            pre = A.PairAddFn.apply(per_pair, no_query, per_ctx, ps)                    # + per_ctx[context row of the pair]
+            m = A.gn_act(pre, gn=self.ctx[0].norm, relu=True)
+            y = A.row_block([target_feat, m], [self.input.weight, self.ctx[1].weight],
+                            [A.Rel(0, 0, L.REL_IDENT), A.Rel(1, 1, L.REL_RANGE)], T, gn=self.norm, relu=True,
+                            rowptr=ps.rowptr, seg_ids=ps.hi, n_seg_rows=ps.n_pairs)
+            y = A.linear_gn(y, m0.linear.weight, gn=m0.norm, relu=True)
+            return A.linear_gn(y, m1.linear.weight, gn=m1.norm, relu=True, res=target_feat)
         per_ctx = ops.agg_mlp(context_feat.shape[0], [ops.RelSpec(context_feat, ops.packed(w0, 0, 128))], 0)
         per_pair = ops.agg_mlp(P, [ops.RelSpec(h.contiguous(), ops.packed(w0, 128, 128))], 0)
         zero_row = torch.zeros((1, ops.C_FEAT), dtype=torch.float32, device=per_pair.device)

@@ -122,47 +122,108 @@ def meta_relu_flips(net, scenes, ref_state_names, seed):
     return [(float(got[i, j]), float(want[i, j])) for i, j in idx.tolist()]
 
 
-def test_training_step_batch32_matches_reference(ref_state_names):
-    """BASELINE config 4: the training step at batch 32 (workload S2, 10,368 nodes / 1,600 actors) against the
-    reference's own loss and gradients (tests/golden/train_b32.npz, make_golden.py): loss scalars, every
-    parameter's gradient norm, and the hot-path gradients of the fixture element-wise (matrices: every 8th row)."""
+def stage_relu_flips(net, scenes, ref_state_names, seed):
+    """ReLU sign flips at the six stage outputs of the hot path (MapNet, A2M.meta, A2M, M2M, M2A, A2A -- each ends in
+    a ReLU) between this build's forward and the oracle's, both fed THIS build's ActorNet output: per stage the number
+    of entries that are zero on one side and positive on the other, and the largest magnitude among them."""
+    import lanegcn_amd  # noqa: F401
+    from lanegcn_amd import lanegcn as M
+    from conftest import to_torch_scene
+    sd = O.seeded_state(ref_state_names, seed)
+    tscenes = [to_torch_scene(s) for s in scenes]
+    out = {}
+    with torch.no_grad():
+        was = net.training
+        net.eval()
+        actors, idcs = M.actor_gather([s["feats"].cuda() for s in tscenes])
+        ctrs = [s["ctrs"].cuda() for s in tscenes]
+        a_in = net.actor_net(actors)
+        graph = M.graph_gather([s["graph"] for s in tscenes])
+        got = {}
+        nodes, nidcs, nctrs = net.map_net(graph)
+        got["map_net"] = nodes
+        got["meta"] = net.a2m.fuse_meta(nodes, graph["turn"], graph["control"], graph["intersect"])
+        got["a2m"] = net.a2m(nodes, graph, a_in, idcs, ctrs)
+        got["m2m"] = net.m2m(got["a2m"], graph)
+        got["m2a"] = net.m2a(a_in, idcs, ctrs, got["m2m"], nidcs, nctrs)
+        got["a2a"] = net.a2a(got["m2a"], idcs, ctrs)
+        net.train(was)
+        g_ref = O.graph_gather([s["graph"] for s in tscenes])
+        want = O.hot_path(g_ref, a_in.cpu(), [s["ctrs"] for s in tscenes], sd)
+        meta_in = torch.cat((want["map_net"], g_ref["turn"], g_ref["control"].unsqueeze(1), g_ref["intersect"].unsqueeze(1)), 1)
+        want["meta"] = O.linear_block(meta_in, sd, "a2m.meta")
+    for k in ("map_net", "meta", "a2m", "m2m", "m2a", "a2a"):
+        a, b = got[k].cpu(), want[k]
+        f = (a > 0) != (b > 0)
+        out[k] = (int(f.sum()), float(torch.maximum(a[f].abs().max(), b[f].abs().max())) if f.any() else 0.0,
+                  float((a - b).abs().max()))
+    return out
+
+
+@pytest.mark.parametrize("mode", ["f32", "f16x2"])
+def test_training_step_batch32_matches_reference(ref_state_names, mode):
+    """BASELINE config 4 (fp32; also in the default f16x2 mode): the training step at batch 32 (workload S2, 10,368
+    nodes / 1,600 actors) against the reference's own loss and gradients (tests/golden/train_b32.npz, make_golden.py):
+    loss scalars, every parameter's gradient norm, and the fixture's gradients element-wise (matrices: every 8th row).
+    The gradient bars are tied to EVIDENCE gathered in the same run: the ReLU sign flips at the stage outputs (a flip
+    is a pre-activation within rounding of zero that lands on the other side under a different summation order; each
+    moves a handful of upstream gradient entries by ~1e-3 of the tensor's scale), counted against the oracle."""
     import lanegcn_amd  # noqa: F401
     from lanegcn_amd import data as gen
     from lanegcn_amd import lanegcn as M
+    from lanegcn_amd import ops
     with np.load(os.path.join(GOLDEN_DIR, "train_b32.npz")) as z:
         tg = {k: z[k] for k in z.files}
-    scenes = gen.synth_batch("S2", seed=int(tg["batch_seed"]))
-    assert len(scenes) == 32
-    net = M.Net(M.config)
-    net.load_state_dict(O.seeded_state(ref_state_names, int(tg["seed"])), strict=True)
-    net = net.cuda().train()
-    batch = gen.collate_fn([gen.from_numpy(s) for s in scenes])
-    loss_out = M.Loss(M.config).cuda()(net(batch), batch)
-    loss_out["loss"].backward()
-    torch.cuda.synchronize()
-    assert loss_out["num_cls"] == int(tg["loss/num_cls"]) and loss_out["num_reg"] == int(tg["loss/num_reg"])
-    for k in ("cls_loss", "reg_loss", "loss"):
-        assert float(loss_out[k].detach()) == pytest.approx(float(tg["loss/" + k]), rel=5e-5), k
-    names = json.load(open(os.path.join(GOLDEN_DIR, "param_names.json")))
-    params = dict(net.named_parameters())
-    norms = np.array([float(params[n].grad.norm()) if params[n].grad is not None else -1.0 for n in names])
-    ref_norms = tg["grad_norms"]
-    bad = [(n, a, b) for n, a, b in zip(names, norms, ref_norms) if abs(a - b) > 3e-3 * b + 1e-6]
-    assert not bad, bad[:5]
-    worst = {}
-    for key, ref in tg.items():
-        if key.startswith("grad/"):
-            g = params[key[5:]].grad.cpu().numpy()
-            g = g[::8] if g.shape != ref.shape else g
-            assert g.shape == ref.shape, key
-            worst[key[5:]] = rel_err(g, ref)
-    # 1.3 M ReLU inputs per layer at this size: a few land on the other side of zero under any change of summation
-    # order, each moves a handful of upstream entries by ~1e-3 of the tensor's scale (see the batch-4 test)
-    assert max(worst.values()) <= 5e-3, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
-    # the median moves from run to run with the same build (seen: 1.5e-4 .. 2.35e-4; alone or behind test_gpu_parity.py it
-    # stays under 2e-4, behind the whole suite it once did not): ActorNet / PredNet train on stock ATen + MIOpen kernels,
-    # whose algorithm choice is per process, and every change of their summation order moves the flips above
-    assert np.median(list(worst.values())) <= 3e-4, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    prev, prev_det, prev_bench = ops.get_mma(), torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark
+    ops.set_mma(mode)
+    torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = True, False      # the stock ops' solver choice pinned
+    try:
+        scenes = gen.synth_batch("S2", seed=int(tg["batch_seed"]))
+        assert len(scenes) == 32
+        net = M.Net(M.config)
+        net.load_state_dict(O.seeded_state(ref_state_names, int(tg["seed"])), strict=True)
+        net = net.cuda().train()
+        batch = gen.collate_fn([gen.from_numpy(s) for s in scenes])
+        loss_out = M.Loss(M.config).cuda()(net(batch), batch)
+        loss_out["loss"].backward()
+        torch.cuda.synchronize()
+        assert loss_out["num_cls"] == int(tg["loss/num_cls"]) and loss_out["num_reg"] == int(tg["loss/num_reg"])
+        for k in ("cls_loss", "reg_loss", "loss"):
+            assert float(loss_out[k].detach()) == pytest.approx(float(tg["loss/" + k]), rel=5e-5), k
+        names = json.load(open(os.path.join(GOLDEN_DIR, "param_names.json")))
+        params = dict(net.named_parameters())
+        norms = np.array([float(params[n].grad.norm()) if params[n].grad is not None else -1.0 for n in names])
+        ref_norms = tg["grad_norms"]
+        bad = [(n, a, b) for n, a, b in zip(names, norms, ref_norms) if abs(a - b) > 3e-3 * b + 1e-6]
+        assert not bad, bad[:5]
+        worst = {}
+        for key, ref in tg.items():
+            if key.startswith("grad/"):
+                g = params[key[5:]].grad.cpu().numpy()
+                g = g[::8] if g.shape != ref.shape else g
+                assert g.shape == ref.shape, key
+                worst[key[5:]] = rel_err(g, ref)
+        flips = stage_relu_flips(net, [gen.from_numpy(s) for s in scenes], ref_state_names, int(tg["seed"]))
+        n_flips = sum(v[0] for v in flips.values())
+        hot = {k: v for k, v in worst.items() if k.split(".")[0] in ("map_net", "a2m", "m2m", "m2a", "a2a")}
+        rest = {k: v for k, v in worst.items() if k not in hot}
+        print("\n[batch-32 step, %s] flips per stage (count, largest |value|, max |delta| of the stage): %s" % (mode, flips))
+        print("[batch-32 step, %s] hot-path gradients: max %.2e median %.2e (%d tensors); other: max %.2e (%d tensors)" %
+              (mode, max(hot.values()), float(np.median(list(hot.values()))), len(hot), max(rest.values()) if rest else 0.0, len(rest)))
+        # every flipped entry sits on the knife edge (|value| at rounding level on both sides), and the forward agrees
+        assert all(v[1] <= 2e-4 for v in flips.values()), flips
+        assert all(v[2] <= 1e-4 for v in flips.values()), flips
+        if n_flips == 0:
+            assert max(hot.values()) <= 1e-4, sorted(hot.items(), key=lambda kv: -kv[1])[:5]
+        else:
+            # the stage outputs are 6 of the ~45 ReLU layers of the hot path (8 LaneConv layers x 2, 6 Att x 4, stems):
+            # flips inside the stages go with the counted ones.  Each moves a few entries by ~1e-3 of a tensor's scale.
+            assert max(hot.values()) <= 5e-3, sorted(hot.items(), key=lambda kv: -kv[1])[:5]
+            assert np.median(list(hot.values())) <= 1e-4 * (1 + n_flips), (n_flips, sorted(hot.items(), key=lambda kv: -kv[1])[:5])
+        assert max(worst.values()) <= 5e-3, sorted(worst.items(), key=lambda kv: -kv[1])[:5]
+    finally:
+        ops.set_mma(prev)
+        torch.backends.cudnn.deterministic, torch.backends.cudnn.benchmark = prev_det, prev_bench
 
 
 def test_training_forward_equals_inference_forward(golden, ref_state_names, mma):

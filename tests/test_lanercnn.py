@@ -80,7 +80,6 @@ def test_hip_modules_vs_reference_captures(fx, mma):
     from lanegcn_amd import lanegcn as M
     from lanegcn_amd import lanercnn as R
     from lanegcn_amd import ops
-    from lanegcn_amd._lib import LgcnError
     prev = ops.get_mma()
     ops.set_mma(mma)
     try:
@@ -110,8 +109,34 @@ def test_hip_modules_vs_reference_captures(fx, mma):
             empty["pre"] = graph["pre"][:-1] + [{"u": graph["pre"][-1]["u"][:0], "v": graph["pre"][-1]["v"][:0]}]
             r = mods["ggn"](torch.relu(x), empty)
             assert isinstance(r, tuple) and len(r) == 1 and r[0].numel() == 0
-        with pytest.raises(LgcnError):
-            mods["pool"](dev(g["pool/cfeat"]).requires_grad_(True), ctx_g, dev(g["pool/tfeat"]), tgt_g, 6.0)
+        # LanePooling / LaneInput under autograd: outputs as under no_grad, gradients of inputs and of every parameter
+        # against torch autograd through the CPU oracle (fp32) on the same weights
+        scenes_c, li_c, ctx_c, tgt_c, _ = inputs(g)
+        sd_pool = OR.seeded_state([(k, tuple(s)) for k, s in names["pool"]], seed + 2)
+        sd_ref = {"pool." + k: v.clone().requires_grad_(True) for k, v in sd_pool.items()}
+        cf_ref, tf_ref = torch.from_numpy(g["pool/cfeat"]).requires_grad_(True), torch.from_numpy(g["pool/tfeat"]).requires_grad_(True)
+        wgt = torch.from_numpy(np.random.default_rng(5).normal(0, 1, g["pool/out"].shape).astype(np.float32))
+        (OR.lane_pooling(cf_ref, ctx_c, tf_ref, tgt_c, sd_ref)[0] * wgt).sum().backward()
+        cf, tf = dev(g["pool/cfeat"]).requires_grad_(True), dev(g["pool/tfeat"]).requires_grad_(True)
+        mods["pool"].zero_grad()
+        out = mods["pool"](cf, ctx_g, tf, tgt_g, 6.0)
+        assert float((out.detach().cpu() - torch.from_numpy(g["pool/out"])).abs().max()) <= FTOL
+        (out * wgt.cuda()).sum().backward()
+        rel = lambda a, b: float((a.cpu() - b).abs().max()) / max(1e-6, float(b.abs().max()))
+        assert rel(cf.grad, cf_ref.grad) <= 2e-4 and rel(tf.grad, tf_ref.grad) <= 2e-4
+        for k, prm in mods["pool"].named_parameters():
+            assert rel(prm.grad, sd_ref["pool." + k].grad) <= 2e-4, k
+        sd_in = OR.seeded_state([(k, tuple(s)) for k, s in names["input"]], seed + 3)
+        sd_ref = {"input." + k: v.clone().requires_grad_(True) for k, v in sd_in.items()}
+        wgt = torch.from_numpy(np.random.default_rng(6).normal(0, 1, g["li/out"].shape).astype(np.float32))
+        (OR.lane_input(li_c, sd_ref) * wgt).sum().backward()
+        mods["input"].zero_grad()
+        mods["input"].train()
+        out = mods["input"](li)
+        assert float((out.detach().cpu() - torch.from_numpy(g["li/out"])).abs().max()) <= FTOL
+        (out * wgt.cuda()).sum().backward()
+        for k, prm in mods["input"].named_parameters():
+            assert rel(prm.grad, sd_ref["input." + k].grad) <= 2e-4, k
         # LaneRoI trains through the LaneConv autograd path
         xr = dev(g["roi/x"]).requires_grad_(True)
         out = mods["roi"](xr, M.graph_gather([s["graph"] for s in scenes]))
