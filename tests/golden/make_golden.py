@@ -421,8 +421,109 @@ def graphgen_fixture():
     np.savez_compressed(os.path.join(HERE, "graphgen_b6.npz"), **out)
 
 
+BIG_SEED = 77
+
+
+def big_inputs(seed=BIG_SEED):
+    """Inputs of the at-size fixtures, regenerated identically by the tests (tests/test_big_fixtures.py imports this
+    function): two lane-graph scenes of 1,080 nodes each, node / target features, two raw lane topologies of >= 1 k nodes."""
+    from lanegcn_amd import data as gen
+    rng = np.random.default_rng(seed)
+    scenes = [gen.synth_scene(rng, [6] * 10, 12), gen.synth_scene(rng, [6] * 10, 9)]
+    n = sum(int(s["graph"]["num_nodes"]) for s in scenes)
+    x = rng.normal(0, 1, (n, 128)).astype(np.float32)
+    cfeat = np.maximum(rng.normal(0, 1, (n, 128)), 0).astype(np.float32)
+    tgt = []
+    for sc in scenes:
+        gr = sc["graph"]
+        pick = rng.choice(int(gr["num_nodes"]), 200, replace=False)
+        c = gr["ctrs"][pick].astype(np.float32) + rng.normal(0, 1.0, (200, 2)).astype(np.float32)
+        tgt.append((c, np.concatenate([c, gr["feats"][pick].astype(np.float32)], 1)))
+    tfeat = np.maximum(rng.normal(0, 1, (400, 128)), 0).astype(np.float32)
+    raw = [graphgen_scene(rng, n_lanes=12, seg_per_lane=40), graphgen_scene(rng, n_lanes=9, seg_per_lane=48, side_p=0.7)]
+    return scenes, x, cfeat, tgt, tfeat, raw
+
+
+def edge_hash(u, v):
+    import hashlib
+    uv = np.stack([np.asarray(u, np.int64), np.asarray(v, np.int64)], 1)
+    uv = uv[np.lexsort((uv[:, 1], uv[:, 0]))]
+    return np.frombuffer(hashlib.sha1(np.ascontiguousarray(uv).tobytes()).digest(), np.uint8).copy(), len(uv)
+
+
+def big_fixture(seed=3):
+    """Rows f3 / f4 AT SIZE (>= 1 k nodes per scene): the reference's own preprocess, data.dilated_nbrs and lanercnn
+    modules on the inputs of big_inputs().  Stored: integer outputs in full (int16 left / right arrays) or as SHA-1 of the
+    sorted edge set (dilated relations, pooling index); feature outputs as every 16th row plus float64 column sums."""
+    import copy
+    import types
+    import torch
+    import_reference()
+    if "torchvision" not in sys.modules:
+        sys.modules["torchvision"] = types.ModuleType("torchvision")
+    import data as refdata
+    import lanegcn as ref
+    import lanercnn as rl
+    import preprocess_data as refpp
+    from oracle.lanercnn_oracle import seeded_state as seeded_rcnn
+    torch.set_num_threads(4)
+    scenes, x, cfeat, tgt, tfeat, raw = big_inputs()
+    out = {"seed": np.int64(seed)}
+    # f3: left / right edges of the raw topologies; dilated pre / suc of the first scene's scale-0 relations
+    for i, g in enumerate(raw):
+        tg = {k: torch.from_numpy(v) for k, v in g.items()}
+        tg["idx"] = i
+        res = refpp.preprocess(tg, 6.0)
+        for side in ("left", "right"):
+            out["pp%d/%s/u" % (i, side)], out["pp%d/%s/v" % (i, side)] = res[side]["u"], res[side]["v"]
+        print("raw topology %d: %d nodes, left %d right %d" % (i, len(g["lane_idcs"]), len(res["left"]["u"]), len(res["right"]["u"])))
+    gr = scenes[0]["graph"]
+    for k1 in ("pre", "suc"):
+        nb = refdata.dilated_nbrs({"u": gr[k1][0]["u"], "v": gr[k1][0]["v"]}, int(gr["num_nodes"]), 6)
+        for j, e in enumerate(nb):
+            h, cnt = edge_hash(e["u"], e["v"])
+            out["dil/%s/%d/sha1" % (k1, j + 1)], out["dil/%s/%d/n" % (k1, j + 1)] = h, np.int64(cnt)
+    # f4: the fork model's graph modules
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    g = ref.graph_gather(ref.to_long(refdata.collate_fn(copy.deepcopy(scenes))["graph"]))
+    mods = {"roi": rl.LaneRoI(rl.config, 128), "ggn": rl.GlobalGraphNet(rl.config), "pool": rl.LanePooling(128, 128)}
+    for i, (name, m) in enumerate(mods.items()):
+        m.eval().load_state_dict(seeded_rcnn([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed + i))
+
+    def keep(key, a):
+        a = a.numpy()
+        out[key + "/rows16"], out[key + "/colsum"] = a[::16].copy(), a.astype(np.float64).sum(0)
+
+    with torch.no_grad():
+        keep("roi", mods["roi"](t(x).clone(), g))
+        keep("ggn", mods["ggn"](torch.relu(t(x).clone()), g))
+        graphs = [s["graph"] for s in scenes]
+        ctx_g = {"ctrs": [t(gr["ctrs"].astype(np.float32)) for gr in graphs],
+                 "pose": [t(np.concatenate([gr["ctrs"], gr["feats"]], 1).astype(np.float32)) for gr in graphs]}
+        tgt_g = {"ctrs": [t(c) for c, _ in tgt], "pose": [t(p_) for _, p_ in tgt]}
+        captured = []
+        real = torch.Tensor.index_add_
+
+        def spy(self, dim, index, source, *a, **k):
+            captured.append(index.numpy().copy())
+            return real(self, dim, index, source, *a, **k)
+
+        torch.Tensor.index_add_ = spy
+        try:
+            keep("pool", mods["pool"](t(cfeat), ctx_g, t(tfeat).clone(), tgt_g, 6.0))
+        finally:
+            torch.Tensor.index_add_ = real
+        import hashlib
+        out["pool/wi_sha1"] = np.frombuffer(hashlib.sha1(np.ascontiguousarray(captured[0].astype(np.int64)).tobytes()).digest(), np.uint8).copy()
+        out["pool/n_pairs"] = np.int64(len(captured[0]))
+    np.savez_compressed(os.path.join(HERE, "big_f3f4.npz"), **out)
+    print("wrote big_f3f4.npz: %d nodes, pooling pairs %d" % (x.shape[0], int(out["pool/n_pairs"])))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "graphgen":
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        big_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == "graphgen":
         graphgen_fixture()
     else:
         main()
