@@ -548,7 +548,7 @@ def main():
         assert all(torch.isfinite(v).all() for v in st.values() if torch.is_tensor(v) and v.is_floating_point())
         f_map = st["nodes"] if args.mapnet_only else st["map_net"]
         f_m2m = st["nodes"] if args.mapnet_only else st["a2m"]
-        for impl in (("fused",) if mma == "f32" else ("fused", "tiled")):
+        for impl in (("fused",) if mma in ("f32", "bf16x3") else ("fused", "tiled")):      # tiled: two- / one-plane modes
             lc_us[impl], lc_launches[impl] = laneconv_launch_us(eng, fb, f_map, f_m2m, impl)
         stages_tab = None if args.mapnet_only or world > 1 else stage_table(eng, fb, actors)
     if world == 1 and not args.mapnet_only and not args.no_graph:
@@ -556,7 +556,7 @@ def main():
             r, e_m = run_mode(args, m, mods, scenes, fb, actors, dev, rank, max(40, args.steps // 2), args.warmup)
             stm = e_m.forward(fb, actors, stages=True)
             lcm = {impl: laneconv_launch_us(e_m, fb, stm["map_net"], stm["a2m"], impl)[0]
-                   for impl in (("fused",) if m == "f32" else ("fused", "tiled"))}
+                   for impl in (("fused",) if m in ("f32", "bf16x3") else ("fused", "tiled"))}
             dom = r["laneconv_impl"]["in_flight"]
             modes[m] = {
                 "value": n_scenes / (r["ms_per_step"] * 1e-3), "unit": "scenes/s", "ms_per_step": r["ms_per_step"],

@@ -35,8 +35,9 @@ constexpr int kLcHdr = 8;                   // int32 words per item header
 template <int F, int V> struct LcCfg;
 template <> struct LcCfg<0, 0> { static constexpr int RBN = 4, CAP = 96, HRB = 2; };      // bf16x3: 768 B per source row
 template <> struct LcCfg<0, 1> { static constexpr int RBN = 8, CAP = 200, HRB = 4; };
-template <> struct LcCfg<1, 0> { static constexpr int RBN = 6, CAP = 144, HRB = 2; };     // f16x2 : 512 B
-template <> struct LcCfg<1, 1> { static constexpr int RBN = 12, CAP = 304, HRB = 6; };
+// (round 3: the f16x2 shapes were 96 / 192 rows and spilled 11-40 registers to scratch; at 64 / 128 rows they do not)
+template <> struct LcCfg<1, 0> { static constexpr int RBN = 4, CAP = 96, HRB = 2; };      // f16x2 : 512 B
+template <> struct LcCfg<1, 1> { static constexpr int RBN = 8, CAP = 208, HRB = 4; };
 template <> struct LcCfg<2, 0> { static constexpr int RBN = 6, CAP = 144, HRB = 2; };     // bf16  : 256 B
 template <> struct LcCfg<2, 1> { static constexpr int RBN = 12, CAP = 304, HRB = 6; };
 // V = 2 "short": 48-row blocks (32 in three planes) within the shared shape's budget (<= 128 VGPRs, <= 79 KB of LDS:
@@ -694,7 +695,6 @@ static bool lc_cfg(int mma, int variant, int *M, int *cap) {
     if (variant < 0 || variant > 2) return false;
 #define LGCN_CFG(F_) do { if (variant == 2) { *M = 16 * LcCfg<F_, 2>::RBN; *cap = LcCfg<F_, 2>::CAP; } else if (variant) { *M = 16 * LcCfg<F_, 1>::RBN; *cap = LcCfg<F_, 1>::CAP; } else { *M = 16 * LcCfg<F_, 0>::RBN; *cap = LcCfg<F_, 0>::CAP; } } while (0)
     switch (fmt_of(mma)) {
-        case 0: LGCN_CFG(0); break;
         case 1: LGCN_CFG(1); break;
         default: LGCN_CFG(2); break;
     }
@@ -713,7 +713,10 @@ extern "C" void lgcn_debug_lc_stamps(void *buf) { g_lc_stamps = reinterpret_cast
 
 extern "C" {
 
-static bool lc_mma_ok(int mma) { return mma == LGCN_MMA_BF16X3 || mma == LGCN_MMA_F16X2 || mma == LGCN_MMA_BF16; }
+// Two- and one-plane modes only.  (Rounds 1-2 also built the three-plane bf16x3 shapes: every one of them spilled
+// registers to scratch and was slower than the one-launch kernel lgcn_agg_mlp runs in that mode; the library ships no
+// kernel that uses scratch -- tests/test_host_cabi.py -- so they are gone: LGCN_ESHAPE, the caller uses lgcn_agg_mlp.)
+static bool lc_mma_ok(int mma) { return mma == LGCN_MMA_F16X2 || mma == LGCN_MMA_BF16; }
 
 int lgcn_lc_config(int mma, int variant, int32_t *rows_per_block, int32_t *cap) {
     if (!lc_mma_ok(mma)) return LGCN_ESHAPE;
@@ -826,7 +829,6 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
         }                                                                                                    \
     } while (0)
     switch (fmt_of(q.mma)) {
-        case 0: LGCN_LC(0); break;
         case 1: LGCN_LC(1); break;
         default: LGCN_LC(2); break;
     }

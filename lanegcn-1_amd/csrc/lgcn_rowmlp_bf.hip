@@ -529,8 +529,10 @@ __device__ __forceinline__ void agg_body(const lgcn_agg_mlp_t &p, int n_tiles, i
 // Tiles of <= 32 rows must keep two 8-wave workgroups per CU (4 waves per SIMD = 128 VGPRs): that co-residency
 // is what hides the weight-fragment latency; the register allocator is held to it (also where that costs a few
 // spilled registers: three-plane bf16x3 at RB = 2 runs 52 us held to 128 VGPRs, 74 us left free).
+// (Round 3: the three-plane kernels are no longer held to 128 VGPRs -- they spilled 10-170 registers to scratch there;
+// the library ships no kernel that uses scratch, tests/test_host_cabi.py.  bf16x3 row blocks run one workgroup per CU.)
 #define LGCN_WAVES_PER_SIMD(RB_, DEEP_, F_) \
-    __attribute__((amdgpu_waves_per_eu(((RB_) <= 2 || ((RB_) == LGCN_RB_ONE && (F_) != 0)) && !(DEEP_) ? 4 : 2)))
+    __attribute__((amdgpu_waves_per_eu((F_) != 0 && ((RB_) <= 2 || (RB_) == LGCN_RB_ONE) && !(DEEP_) ? 4 : 2)))
 
 template <int RB, int F, int KIND, bool DEEP>
 __global__ __launch_bounds__(512) LGCN_WAVES_PER_SIMD(RB, DEEP, F) void k_agg_mlp_bf(const lgcn_agg_mlp_t p, int n_tiles) {
@@ -707,7 +709,7 @@ static int cu_count() {
 // set through its CU's L1 once per relation).
 static int pick_rb(int64_t n_rows, int fmt, bool lane_conv = false) {
     const int64_t n_sub = (n_rows + 15) / 16;
-    auto slots = [&](int rb) { return (int64_t)cu_count() * (rb <= 2 || (rb == LGCN_RB_ONE && fmt != 0) ? 2 : 1); };
+    auto slots = [&](int rb) { return (int64_t)cu_count() * (fmt != 0 && (rb <= 2 || rb == LGCN_RB_ONE) ? 2 : 1); };
     auto tiles = [&](int rb) { return (n_sub + rb - 1) / rb; };
     // LaneConv with several forwards in flight: once 32-row tiles would put two workgroups on some CUs (more tiles
     // than CUs), 48-row tiles are the better unit -- they still run two per CU (one-set weight ring, 126 VGPRs,
@@ -763,11 +765,21 @@ int agg_mlp_bf(const lgcn_agg_mlp_t &p, bool lane_conv, hipStream_t st) {
     if (rb < 0 || rb > 4) return LGCN_EINVAL;
     if (rb == 0 && lane_conv && force_rb_lc >= 1 && force_rb_lc <= 4) rb = force_rb_lc;
     if (rb == 0) rb = force_rb >= 1 && force_rb <= 4 ? force_rb : pick_rb(p.n_rows, fmt_of(p.mma), lane_conv);
-    const bool deep = ring >= 3;   // measured: no gain for the small row blocks either (U/V, Att tails)
+#ifdef LGCN_TUNING      // the deep weight ring (measured: no gain, also for the small row blocks) exists in the tuning builds only
+    if (ring >= 3) {
+        switch (fmt_of(p.mma)) {
+            case 0: launch_agg<0, true>(p, rb, lane_conv, st); break;
+            case 1: launch_agg<1, true>(p, rb, lane_conv, st); break;
+            default: launch_agg<2, true>(p, rb, lane_conv, st); break;
+        }
+        return launch_status();
+    }
+#endif
+    (void)ring;
     switch (fmt_of(p.mma)) {
-        case 0: if (deep) launch_agg<0, true>(p, rb, lane_conv, st); else launch_agg<0, false>(p, rb, lane_conv, st); break;
-        case 1: if (deep) launch_agg<1, true>(p, rb, lane_conv, st); else launch_agg<1, false>(p, rb, lane_conv, st); break;
-        default: if (deep) launch_agg<2, true>(p, rb, lane_conv, st); else launch_agg<2, false>(p, rb, lane_conv, st); break;
+        case 0: launch_agg<0, false>(p, rb, lane_conv, st); break;
+        case 1: launch_agg<1, false>(p, rb, lane_conv, st); break;
+        default: launch_agg<2, false>(p, rb, lane_conv, st); break;
     }
     return launch_status();
 }

@@ -819,10 +819,11 @@ class LcPlan:
 
 def lc_config(mma: Optional[int] = None, variant: int = 0):
     """(rows_per_block, LDS source-row capacity) of a matrix mode (variant 0: shared, 1: tall, 2: short);
-    None for LGCN_MMA_F32 (lgcn_agg_mlp path)."""
+    None for LGCN_MMA_F32 and LGCN_MMA_BF16X3: those modes run the one-launch lgcn_agg_mlp LaneConv (the three-plane
+    shapes of the weight-stationary kernel needed scratch and were slower: removed in round 3)."""
     lib = L.load()
     mma = _mma if mma is None else mma
-    if mma == L.MMA_F32:
+    if mma in (L.MMA_F32, L.MMA_BF16X3):
         return None
     m, c = C.c_int32(), C.c_int32()
     L.check(lib.lgcn_lc_config(mma, variant, C.byref(m), C.byref(c)), "lgcn_lc_config")

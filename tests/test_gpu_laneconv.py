@@ -76,8 +76,14 @@ def check_plan(ops, lane, n_groups, cap, variant=0):
     return lcp
 
 
+def needs_tiled(ops):
+    if ops.lc_config() is None:
+        pytest.skip("this matrix mode runs LaneConv on lgcn_agg_mlp (no weight-stationary kernel: round 3)")
+
+
 def test_plan_bit_exact_multigraph(hip):
     M, ops = hip
+    needs_tiled(ops)
     rng = np.random.default_rng(17)
     n = 16 * 23 + 5
     us, vs = coo(multigraph(rng, n))
@@ -90,6 +96,7 @@ def test_plan_bit_exact_multigraph(hip):
 
 def test_plan_bit_exact_synthetic_scenes(hip):
     M, ops = hip
+    needs_tiled(ops)
     from lanegcn_amd import data as gen
     scenes = [to_torch_scene(s) for s in gen.synth_batch("S2", seed=3, n_scenes=3)]
     graph = M.graph_gather([s["graph"] for s in scenes])
@@ -132,9 +139,9 @@ def test_layer_vs_oracle_and_fused_kernel(hip, ref_state_names):
         lane = ops.csr_build([u.cuda() for u in us], [v.cuda() for v in vs], n)
         fused = M.lane_conv(m2m.fuse, feat.cuda(), lane, 6, impl="fused").cpu().numpy()
         assert float(np.abs(fused - want).max()) <= FTOL
-        got = M.lane_conv(m2m.fuse, feat.cuda(), lane, 6, impl="tiled").cpu().numpy()     # default plan
+        got = M.lane_conv(m2m.fuse, feat.cuda(), lane, 6, impl="tiled").cpu().numpy()     # default plan (bf16x3: the one-launch kernel)
         assert float(np.abs(got - want).max()) <= FTOL
-        for variant in (0, 1, 2):
+        for variant in ((0, 1, 2) if ops.lc_config() is not None else ()):
             m_rows, _ = ops.lc_config(variant=variant)
             # one group = the layer is finished inside the launch; several = partial sums + combine launch;
             # cap = m_rows forces the plan to split groups into several items
