@@ -435,6 +435,9 @@ typedef struct {
     int32_t mma;
     float *part;                      /* workspace                               */
     float *out;                       /* [N,128]                                 */
+    int32_t waves;                    /* 0 / 8: 8-wave workgroups (K in two parts); 16: 16-wave workgroups, K in four
+                                         parts -- the "short" shape with n_groups = 1 only (else LGCN_EINVAL): four
+                                         waves per SIMD from ONE workgroup, for one forward at a time */
 } lgcn_laneconv_t;
 int lgcn_lc_config(int mma, int variant, int32_t *rows_per_block, int32_t *cap);
 int64_t lgcn_lc_plan_elems(int64_t n_nodes, int rows_per_block, int cap);

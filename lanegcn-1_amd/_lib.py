@@ -76,7 +76,7 @@ class LaneConv(C.Structure):      # lgcn_laneconv_t
         ("rows_per_block", C.c_int32), ("cap", C.c_int32), ("n_units", C.c_int32), ("n_groups", C.c_int32),
         ("gstart", C.c_int32 * (LC_UNITS + 1)),
         ("gn1_g", C.c_void_p), ("gn1_b", C.c_void_p), ("wp2", C.c_void_p), ("gn2_g", C.c_void_p), ("gn2_b", C.c_void_p),
-        ("eps", C.c_float), ("mma", C.c_int32), ("part", C.c_void_p), ("out", C.c_void_p),
+        ("eps", C.c_float), ("mma", C.c_int32), ("part", C.c_void_p), ("out", C.c_void_p), ("waves", C.c_int32),
     ]
 
 

@@ -262,8 +262,8 @@ __device__ __forceinline__ void lc_split_store(unsigned char *smem, int s, int l
     }
 }
 
-template <int F>
-struct LcW { uint4 v[Fmt<F>::NP][2][2]; };     // [plane][K-step of this wave's half][16-channel block]
+template <int F, int KSW = 2>
+struct LcW { uint4 v[Fmt<F>::NP][KSW][2]; };     // [plane][K-step of this wave's part of K][16-channel block]
 
 // LDS geometry of one (format, row-block height) instance.  Main loop: (CAP + 1) source rows.  Epilogue, per
 // phase of HR rows: (finishing launches) the Y operand planes at LDS rows 0 .. HR, then the two K halves' fp32 tiles
@@ -280,17 +280,23 @@ struct LcGeom {
                   "row block does not fit the LDS");
 };
 
-template <int F, int V, bool FIN>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(V == 1 ? 2 : 4)))
+// KP = parts K is split into = waves per channel quarter: 2 (8 waves, every shape) or 4 (16 waves, round 3: the "short"
+// shape for ONE forward at a time -- four waves per SIMD from a single workgroup, each with half the MFMAs, weight
+// loads and LDS reads per unit; the four partial tiles meet in two steps in the epilogue).
+template <int F, int V, bool FIN, int KP = 2>
+__global__ __launch_bounds__(256 * KP) __attribute__((amdgpu_waves_per_eu(V == 1 ? 2 : 4)))
 void k_lc_tile(const LcTileParams p) {
     using G = LcGeom<F, V>;
     constexpr int RBN = G::RBN, CAP = G::CAP, NP = G::NP, ROWB = G::ROWB, M = G::M, HRB = G::HRB, HR = G::HR, PH = G::PH;
-    constexpr int NIT = (CAP + 15) / 16;
+    constexpr int NT = 256 * KP, KSW = 4 / KP;         // threads (4 channel quarters x KP parts of K, one wave each); K-steps (of 32) per wave
+    constexpr int HWS = NT / 32, RPS = NT / 8;         // half-waves (one source row each per loader step); rows per row-phase sweep
+    constexpr int NIT = (CAP + HWS - 1) / HWS;
     constexpr bool DBUF = V == 1;                      // tall: a second weight-slice register set (256 VGPRs to spend)
+    static_assert(KP == 2 || (KP == 4 && !DBUF), "K in two parts (8 waves) or four (16 waves, not the tall shape)");
     constexpr int NLC = RBN > 8 ? 2 : 1;               // uint4 words of the per-row index
     __shared__ __attribute__((aligned(16))) unsigned char smem[G::SMEM];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cq = wave & 3, kh = wave >> 2;          // channel quarter, half of K
+    const int cq = wave & 3, kh = wave >> 2;          // channel quarter, part of K (0 .. KP - 1)
     const int kq = lane >> 4;
     const int item0 = xcd_chunk_remap(blockIdx.x, p.n_blocks * p.n_groups);
     const int b = item0 / p.n_groups, g = item0 % p.n_groups;
@@ -316,9 +322,9 @@ void k_lc_tile(const LcTileParams p) {
 
     f32x4 acc[RBN][2];
     acc_zero<RBN>(acc);
-    LcW<F> wc, wn;                                     // wn is used by the tall shape only
+    LcW<F, KSW> wc, wn;                                // wn is used by the tall shape only
     uint4 lc[NLC], ln[NLC];
-    auto load_w_ks = [&](const float *wp, LcW<F> &w, int ks) {     // K-step ks of this wave's weight slice
+    auto load_w_ks = [&](const float *wp, LcW<F, KSW> &w, int ks) {     // K-step ks of this wave's weight slice
         // explicitly a GLOBAL pointer: behind the scalar-register pin below the compiler no longer infers the address
         // space, and a flat load would count on lgkmcnt too (every wait for it would drain the LDS reads in flight)
         typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
@@ -328,7 +334,7 @@ void k_lc_tile(const LcTileParams p) {
         for (int pl = 0; pl < NP; ++pl)
 #pragma unroll
             for (int cb = 0; cb < 2; ++cb)
-                w.v[pl][ks][cb] = __builtin_bit_cast(uint4, u32x4_t(Wp[((((pl * 4 + cq) * 4 + (2 * kh + ks)) * 2 + cb) << 6) + lane]));
+                w.v[pl][ks][cb] = __builtin_bit_cast(uint4, u32x4_t(Wp[((((pl * 4 + cq) * 4 + (KSW * kh + ks)) * 2 + cb) << 6) + lane]));
     };
     auto load_loc = [&](int uu, uint4 (&lo)[NLC]) {
         const uint4 *lp = locp + (((int64_t)b * kLcUnits + uu) * 256 * 2) / 16 + (lane & 15) * 2;
@@ -338,7 +344,7 @@ void k_lc_tile(const LcTileParams p) {
     // one K = 128 pass over sub-blocks whose LDS rows are given per lane: the A fragments of K-step ks of sub-block
     // rb + 1 are requested as soon as the MFMAs of K-step ks of sub-block rb have consumed their registers
     auto rd = [&](uint32_t row, int ks, uint4 (&a)[NP]) {
-        const uint32_t slot = (uint32_t)(((2 * kh + ks) << 2) | kq) ^ (row & 15u);
+        const uint32_t slot = (uint32_t)(((KSW * kh + ks) << 2) | kq) ^ (row & 15u);
         const unsigned char *q = smem + row * ROWB + (slot << 4);
 #pragma unroll
         for (int pl = 0; pl < NP; ++pl) a[pl] = *reinterpret_cast<const uint4 *>(q + pl * 256);
@@ -346,7 +352,7 @@ void k_lc_tile(const LcTileParams p) {
     // The weight slice is the FIRST matrix operand and the rows the second (D^T = W^T X^T; the two operands have the
     // same register layout): a lane then holds 4 CONSECUTIVE channels of row (lane & 15), so the accumulators go to
     // the fp32 tiles as 16-byte stores.
-    auto mmw = [&](f32x4 (&c2)[2], int ks, const uint4 (&a)[NP], const LcW<F> &w) {
+    auto mmw = [&](f32x4 (&c2)[2], int ks, const uint4 (&a)[NP], const LcW<F, KSW> &w) {
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
             f32x4 c = c2[cb];
@@ -380,7 +386,7 @@ void k_lc_tile(const LcTileParams p) {
             const int2 *sl = srcp + item * p.cap;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {      // unconditional loads (index clamped): one round trip for all
-                const int s = it * 16 + hw;
+                const int s = it * HWS + hw;
                 e[it] = sl[s < p.cap ? s : p.cap - 1];
             }
         }
@@ -410,8 +416,8 @@ void k_lc_tile(const LcTileParams p) {
         };
         const int uf = unit_at(0);
         if (DBUF) {       // tall shape: registers to spare, the slice arrives under the loader
-            load_w_ks(wptr(uf), wc, 0);
-            load_w_ks(wptr(uf), wc, 1);
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) load_w_ks(wptr(uf), wc, ks);
             load_loc(uf, lc);
         }
         // the zero row and (below) the unit list are written by EVERY thread, redundantly, rather than by the first
@@ -426,7 +432,7 @@ void k_lc_tile(const LcTileParams p) {
             const int hw = (tid >> 5) + opq, l = (tid & 31) + opq;
 #pragma unroll
             for (int it = 0; it < NIT; ++it)
-                if (it * 16 + hw >= n_src) e[it] = make_int2(0, -1);   // y < 0: no row
+                if (it * HWS + hw >= n_src) e[it] = make_int2(0, -1);   // y < 0: no row
             constexpr int NH = DBUF ? (NIT + 1) / 2 : (NIT + 1) / 2 < 5 ? (NIT + 1) / 2 : 5;   // row loads in flight per lane (registers)
 #pragma unroll
             for (int h0 = 0; h0 < NIT; h0 += NH) {
@@ -448,12 +454,12 @@ void k_lc_tile(const LcTileParams p) {
                 }
 #pragma unroll
                 for (int j = 0; j < NH; ++j)
-                    if (h0 + j < NIT && e[h0 + j].y >= 0) lc_split_store<F>(smem, (h0 + j) * 16 + hw, l, v[j]);
+                    if (h0 + j < NIT && e[h0 + j].y >= 0) lc_split_store<F>(smem, (h0 + j) * HWS + hw, l, v[j]);
             }
         }
         if (!DBUF) {      // shared shape: requested behind the row loads; arrives under the barrier / the other workgroup
-            load_w_ks(wptr(uf), wc, 0);
-            load_w_ks(wptr(uf), wc, 1);
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) load_w_ks(wptr(uf), wc, ks);
             load_loc(uf, lc);
         }
         LC_STAMP();   // own source rows stored
@@ -473,7 +479,10 @@ void k_lc_tile(const LcTileParams p) {
 #ifdef LGCN_STAMPS
                 if (p.exp & 1) wn = wc; else
 #endif
-                if (more || tail2) { load_w_ks(wnext, wn, 0); load_w_ks(wnext, wn, 1); }
+                if (more || tail2) {
+#pragma unroll
+                    for (int ks = 0; ks < KSW; ++ks) load_w_ks(wnext, wn, ks);
+                }
                 if (more) load_loc(un, ln);
             }
             uint32_t lw[4 * NLC];
@@ -483,21 +492,19 @@ void k_lc_tile(const LcTileParams p) {
                 const uint32_t w16 = (lw[rb >> 1] >> (16 * (rb & 1))) & 0xffffu;
                 return w16 == 0xffffu ? (uint32_t)CAP : w16;
             };
-            uint4 a0[NP], a1[NP];
-            rd(row_of(0), 0, a0);
-            rd(row_of(0), 1, a1);
+            uint4 ak[KSW][NP];
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) rd(row_of(0), ks, ak[ks]);
 #pragma unroll
             for (int rb = 0; rb < RBN; ++rb) {
-                __builtin_amdgcn_sched_barrier(0);
-                mm(acc[rb], 0, a0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (rb + 1 < RBN) rd(row_of(rb + 1), 0, a0);
-                else if (!DBUF && (more || tail2)) load_w_ks(wnext, wc, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(acc[rb], 1, a1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (rb + 1 < RBN) rd(row_of(rb + 1), 1, a1);
-                else if (!DBUF && (more || tail2)) load_w_ks(wnext, wc, 1);
+#pragma unroll
+                for (int ks = 0; ks < KSW; ++ks) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(acc[rb], ks, ak[ks]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (rb + 1 < RBN) rd(row_of(rb + 1), ks, ak[ks]);
+                    else if (!DBUF && (more || tail2)) load_w_ks(wnext, wc, ks);
+                }
             }
             if (DBUF) {
                 if (more || tail2) wc = wn;
@@ -519,19 +526,37 @@ void k_lc_tile(const LcTileParams p) {
     // add the two tiles on the way out (8 threads per row, 512-B coalesced rows).  A finishing launch goes on:
     // GN -> ReLU -> operand planes -> ctr2 on the matrix cores (same K split) -> GN -> + X -> ReLU -> out.
     float *T0 = reinterpret_cast<float *>(smem + G::TOFF);
-    float *Tk = T0 + kh * (HR * kLDA);
-    constexpr int SW = (HR + 63) / 64;              // sweeps of 64 rows
+    float *Tk = T0 + (kh & 1) * (HR * kLDA);
+    constexpr int SW = (HR + RPS - 1) / RPS;        // sweeps of RPS rows (8 threads per row)
+    // the K parts' accumulators -> the two fp32 tiles T0 | T1.  Four parts: parts 0, 1 store, a barrier, parts 2, 3 add
+    // theirs onto T0 / T1 (every element is touched by exactly one lane of one wave per step: no atomics).  Ends with the
+    // tiles complete and a workgroup barrier passed.
     auto tiles_from_acc = [&](int ph) {
+        if (KP == 2 || kh < 2) {
 #pragma unroll
-        for (int rb = 0; rb < HRB; ++rb)
+            for (int rb = 0; rb < HRB; ++rb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-                *reinterpret_cast<f32x4 *>(Tk + (16 * rb + (lane & 15)) * kLDA + 32 * cq + 16 * cb + 4 * (lane >> 4)) =
-                    acc[ph * HRB + rb][cb];
+                for (int cb = 0; cb < 2; ++cb)
+                    *reinterpret_cast<f32x4 *>(Tk + (16 * rb + (lane & 15)) * kLDA + 32 * cq + 16 * cb + 4 * (lane >> 4)) =
+                        acc[ph * HRB + rb][cb];
+        }
+        lds_barrier();
+        if (KP == 4) {
+            if (kh >= 2) {
+#pragma unroll
+                for (int rb = 0; rb < HRB; ++rb)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        f32x4 *q = reinterpret_cast<f32x4 *>(Tk + (16 * rb + (lane & 15)) * kLDA + 32 * cq + 16 * cb + 4 * (lane >> 4));
+                        *q = *q + acc[ph * HRB + rb][cb];
+                    }
+            }
+            lds_barrier();
+        }
     };
     auto tile_row = [&](int sweep) {
-        RowVals r = row_load(T0 + sweep * 64 * kLDA, tid);
-        row_add(r, row_load(T0 + (HR + sweep * 64) * kLDA, tid));
+        RowVals r = row_load(T0 + sweep * RPS * kLDA, tid);
+        row_add(r, row_load(T0 + (HR + sweep * RPS) * kLDA, tid));
         return r;
     };
     LC_STAMP();           // epilogue starts
@@ -541,18 +566,17 @@ void k_lc_tile(const LcTileParams p) {
         if (finish) {     // residual rows: requested here, used at the very end of the phase
 #pragma unroll
             for (int sweep = 0; sweep < SW; ++sweep) {
-                const int64_t n = (int64_t)b * M + ph * HR + sweep * 64 + (tid >> 3);
+                const int64_t n = (int64_t)b * M + ph * HR + sweep * RPS + (tid >> 3);
                 const float *rp_ = p.x + (n < p.n_rows ? n : 0) * kC + 4 * (tid & 7);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) resv[sweep].v[j] = *reinterpret_cast<const float4 *>(rp_ + 32 * j);
             }
         }
         tiles_from_acc(ph);
-        lds_barrier();
-        LC_STAMP();       // both K halves of this row half in LDS
+        LC_STAMP();       // the K parts of this row half in LDS
 #pragma unroll
         for (int sweep = 0; sweep < SW; ++sweep) {
-            const int hrow = sweep * 64 + (tid >> 3);
+            const int hrow = sweep * RPS + (tid >> 3);
             if (hrow < HR) {
                 RowVals r = tile_row(sweep);
                 const int row = ph * HR + hrow;
@@ -576,26 +600,24 @@ void k_lc_tile(const LcTileParams p) {
                 acc[ph * HRB + rb][0] = zero4;
                 acc[ph * HRB + rb][1] = zero4;
             }
-            uint4 a0[NP], a1[NP];
+            uint4 ak[KSW][NP];
             const uint32_t yrow = (uint32_t)G::YR0 + (lane & 15);
-            rd(yrow, 0, a0);
-            rd(yrow, 1, a1);
+#pragma unroll
+            for (int ks = 0; ks < KSW; ++ks) rd(yrow, ks, ak[ks]);
 #pragma unroll
             for (int rb = 0; rb < HRB; ++rb) {
-                __builtin_amdgcn_sched_barrier(0);
-                mm(acc[ph * HRB + rb], 0, a0);
-                __builtin_amdgcn_sched_barrier(0);
-                if (rb + 1 < HRB) rd(yrow + 16 * (rb + 1), 0, a0);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(acc[ph * HRB + rb], 1, a1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (rb + 1 < HRB) rd(yrow + 16 * (rb + 1), 1, a1);
+#pragma unroll
+                for (int ks = 0; ks < KSW; ++ks) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(acc[ph * HRB + rb], ks, ak[ks]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (rb + 1 < HRB) rd(yrow + 16 * (rb + 1), ks, ak[ks]);
+                }
             }
             tiles_from_acc(ph);       // T0 | T1 and the Y planes are disjoint
-            lds_barrier();
 #pragma unroll
             for (int sweep = 0; sweep < SW; ++sweep) {
-                const int hrow = sweep * 64 + (tid >> 3);
+                const int hrow = sweep * RPS + (tid >> 3);
                 const int64_t n = (int64_t)b * M + ph * HR + hrow;
                 if (hrow < HR) {
                     RowVals r = tile_row(sweep);
@@ -785,6 +807,7 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
     }
     if (q.n_rows < 0 || variant < 0 || q.cap < M || q.cap > capv || q.n_rows > 0x7fffffff) return LGCN_EINVAL;
     if (!lc_groups_ok(q.n_units, q.n_groups, q.gstart)) return LGCN_EINVAL;
+    if (q.waves != 0 && q.waves != 8 && !(q.waves == 16 && variant == 2 && q.n_groups == 1)) return LGCN_EINVAL;
     if (q.n_rows == 0) return LGCN_OK;
     const void *ptrs[] = {q.x, q.plan, q.out, q.wp2, q.gn1_g, q.gn1_b, q.gn2_g, q.gn2_b};
     for (const void *v : ptrs) { LGCN_CHECK_PTR(v); LGCN_CHECK_ALIGN16(v); }
@@ -822,7 +845,8 @@ int lgcn_laneconv_fwd(const lgcn_laneconv_t *ph, void *stream) {
     } while (0)
 #define LGCN_LC(F_)                                                                                          \
     do {                                                                                                     \
-        if (q.n_groups == 1) LGCN_LCV(F_, true);                                                             \
+        if (q.waves == 16) hipLaunchKernelGGL((k_lc_tile<F_, 2, true, 4>), dim3(grid1), dim3(1024), 0, st, t); \
+        else if (q.n_groups == 1) LGCN_LCV(F_, true);                                                        \
         else {                                                                                               \
             LGCN_LCV(F_, false);                                                                             \
             hipLaunchKernelGGL((k_lc_combine<F_>), dim3(n_tiles), dim3(256), 0, st, c, n_tiles);             \

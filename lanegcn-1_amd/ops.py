@@ -951,10 +951,28 @@ def lc_part(lcp: LcPlan) -> Optional[torch.Tensor]:
     return torch.empty(n, dtype=torch.float32, device=lcp.plan.device)
 
 
+_lc_waves = int(os.environ.get("LGCN_LC_WAVES", "0"))      # 16: 16-wave workgroups for the short one-group shape
+
+
+def set_lc_waves(n: int):
+    """Waves per LaneConv workgroup of the short, one-group shape: 0 / 8 (default) or 16 (K split four ways: four waves
+    per SIMD from one workgroup -- for ONE forward at a time; with several forwards in flight two 8-wave workgroups of
+    different forwards share a CU instead)."""
+    global _lc_waves
+    if n not in (0, 8, 16):
+        raise L.LgcnError("LaneConv workgroups have 8 or 16 waves")
+    _lc_waves = n
+
+
+def lc_waves() -> int:
+    return _lc_waves
+
+
 def laneconv_fwd(x: torch.Tensor, lcp: LcPlan, wps: Sequence[Optional[torch.Tensor]], gn1, wp2, gn2, eps=EPS,
-                 part: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tag="laneconv"):
+                 part: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, tag="laneconv",
+                 waves: Optional[int] = None):
     """One LaneConv layer (lgcn_laneconv_fwd): wps[u] = packed weight of unit u (ctr, then the plan's relations;
-    None for a relation without edges)."""
+    None for a relation without edges).  waves: None = the module setting (set_lc_waves) where the plan allows it."""
     lib = L.load()
     x = _dev(x, torch.float32, "x")
     if x.shape[0] != lcp.lane.n_nodes or len(wps) != lcp.n_units:
@@ -969,6 +987,9 @@ def laneconv_fwd(x: torch.Tensor, lcp: LcPlan, wps: Sequence[Optional[torch.Tens
         p.gstart[g] = v
     p.gn1_g, p.gn1_b, p.wp2, p.gn2_g, p.gn2_b = gn1[0].data_ptr(), gn1[1].data_ptr(), wp2.data_ptr(), gn2[0].data_ptr(), gn2[1].data_ptr()
     p.eps, p.mma = eps, _mma
+    short = lc_config(variant=2)
+    w = _lc_waves if waves is None else waves
+    p.waves = 16 if (w == 16 and short is not None and lcp.rows_per_block == short[0] and len(lcp.gstart) == 2) else 0
     if part is None:
         part = lc_part(lcp)
     if out is None:

@@ -152,6 +152,44 @@ def test_layer_vs_oracle_and_fused_kernel(hip, ref_state_names):
                 assert float(np.abs(got - fused).max()) <= 2e-5, (variant, n_groups, cap)
 
 
+def test_sixteen_wave_short_shape(hip, ref_state_names):
+    """lgcn_laneconv_fwd with waves = 16 (K split four ways, the four partial tiles merged in two steps) on the short
+    one-group shape: against the oracle and the 8-wave launch, ragged row count, multigraph; refused for other shapes."""
+    M, ops = hip
+    needs_tiled(ops)
+    rng = np.random.default_rng(23)
+    n = 48 * 7 + 19
+    sd = O.seeded_state(ref_state_names, 11)
+    m2m = M.M2M(M.config)
+    m2m.load_state_dict({k[4:]: v for k, v in sd.items() if k.startswith("m2m.")})
+    m2m = m2m.cuda().eval()
+    graph = multigraph(rng, n)
+    feat = torch.from_numpy(rng.normal(0, 1, (n, 128)).astype(np.float32)).relu()
+    want = O.m2m(feat, graph, sd).numpy()
+    us, vs = coo(graph)
+    keys = M.rel_keys(6)
+    with torch.no_grad():
+        lane = ops.csr_build([u.cuda() for u in us], [v.cuda() for v in vs], n)
+        lcp = ops.lc_plan(lane, n_groups=1, variant=2)
+
+        def layers(waves, plan=lcp):
+            x = feat.cuda()
+            for i in range(4):
+                wps = [ops.packed(m2m.fuse["ctr"][i].weight)]
+                wps += [ops.packed(m2m.fuse[k][i].weight) if lane.n_edges[r] > 0 else None for r, k in enumerate(keys)]
+                c2 = m2m.fuse["ctr2"][i]
+                x = ops.laneconv_fwd(x, plan, wps, M._gn(m2m.fuse["norm"][i]), ops.packed(c2.linear.weight), M._gn(c2.norm), waves=waves)
+            return x.cpu().numpy()
+
+        a8, a16 = layers(8), layers(16)
+        assert float(np.abs(a16 - want).max()) <= FTOL
+        assert float(np.abs(a16 - a8).max()) <= 2e-5
+        assert np.array_equal(a16, layers(16)), "not bitwise repeatable"
+        # other shapes / several groups: the request is ignored by ops (8 waves) and refused by the C ABI
+        other = ops.lc_plan(lane, n_groups=1, variant=0)
+        assert np.array_equal(layers(16, other), layers(8, other))
+
+
 def test_mapnet_s1_vs_oracle(hip, ref_state_names):
     """BASELINE config 2: MapNet only on the one merged 10,008-node / 59,952-edge graph (S1), vs the oracle."""
     M, ops = hip
