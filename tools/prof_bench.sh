@@ -7,5 +7,6 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$root/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d "$root/gpurun_out/$name" -o "$name" -- python3 "$root/bench.py" "$@" > "$root/gpurun_out/$name.log" 2>&1
-find "$root/gpurun_out/$name" -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} "$root/gpurun_out/${name}_kernel_stats.csv"
-head -30 "$root/gpurun_out/${name}_kernel_stats.csv" | cut -c1-160
+# ROCm 7.2 writes a rocpd SQLite file (<name>_results.db), no CSV: tools/rocpd_stats.py makes the per-kernel table
+db=$(find "$root/gpurun_out/$name" -name "*_results.db" | sort | tail -1)
+python3 "$root/tools/rocpd_stats.py" "$db" "$root/gpurun_out/${name}_kernel_stats.csv" | cut -c1-160 | sed -n 1,30p
