@@ -61,6 +61,25 @@ def test_no_shipped_kernel_uses_scratch():
     assert not bad, bad
 
 
+def test_no_shipped_kernel_holds_the_miscomputed_packed_form():
+    """MI355X returns wrong low halves in lanes 48-63 for a packed fp32 instruction whose low result lane reads the high
+    half of its second source (op_sel[1] = 1: v_pk_mul_f32 / v_pk_add_f32 d, a, b op_sel:[0,1] ...) while other waves of
+    the CU issue MFMA / LDS instructions (tools/micro/pk_opsel.hip; the cause of the wrong rows of rounds 2 / 3,
+    DESIGN.md section 3.1).  The library is built without the SLP vectoriser that emits it; this disassembles the shipped
+    code objects and checks."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    if not os.path.exists(kr.OBJDUMP):
+        pytest.skip("llvm-objdump not found")
+    found = kr.risky_packed(os.path.join(ROOT, "lanegcn-1_amd", "liblgcn.so"))
+    assert not found, found[:5]
+    # the detector itself: the compare + select diagnostic build (SLP on) is where the form was first seen
+    diag = os.path.join(ROOT, "lanegcn-1_amd", "liblgcn_relucnd.so")
+    if os.path.exists(diag):
+        assert kr.risky_packed(diag), "detector finds nothing in the build that is known to hold the form"
+
+
 def test_size_helpers(lib):
     l, _ = lib
     assert l.lgcn_csr_rowptr_elems(10368, 14) == 648 * 14 * 16 + 1

@@ -1,8 +1,14 @@
 """Per-kernel resources of a HIP shared library, read from the code objects embedded in it (no GPU, no ROCm tools):
 name, VGPRs, spilled VGPRs, private-segment (scratch) bytes, LDS bytes.  `python tools/kernel_resources.py [lib.so]`
-prints the table; tests/test_host_cabi.py uses kernels() to assert that no shipped kernel uses scratch."""
+prints the table; tests/test_host_cabi.py uses kernels() to assert that no shipped kernel uses scratch, and
+risky_packed() (llvm-objdump of the same code objects) to assert that none holds the packed fp32 instruction form that
+MI355X miscomputes in lanes 48-63 (tools/micro/pk_opsel.hip)."""
+import os
+import re
 import struct
+import subprocess
 import sys
+import tempfile
 
 import msgpack
 
@@ -63,9 +69,42 @@ def kernels(path):
     return out
 
 
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+_PK = re.compile(r"^\s*(v_pk_(?:mul|add|fma|min|max)\w*_f32)\s+(v\[[0-9:]+\]),\s*([^,]+),\s*([^, ]+)(?:,\s*[^, ]+)?\s*(.*?)\s*(?://.*)?$")
+
+
+def risky_packed(path):
+    """[(kernel, instruction)] for every packed fp32 arithmetic instruction of the library whose LOW result lane reads
+    the HIGH half of its second source (op_sel[1] = 1) from a register pair other than the first source's: the form
+    that returns wrong low halves in lanes 48-63 next to MFMA / LDS traffic (v_pk_add_f32 a, a op_sel:[0,1]
+    op_sel_hi:[1,0], the horizontal add of one pair, and every op_sel_hi form measured clean)."""
+    blob = open(path, "rb").read()
+    out = []
+    for triple, elf in _code_objects(blob):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(elf)
+            f.flush()
+            text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+        kern = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                kern = m.group(1)
+                continue
+            m = _PK.match(line)
+            if not m:
+                continue
+            op, _dst, s0, s1, mods = m.groups()
+            sel = re.search(r"op_sel:\[([0-9,]+)\]", mods)
+            if sel is None:
+                continue
+            bits = [int(x) for x in sel.group(1).split(",")]
+            if len(bits) > 1 and bits[1] == 1 and s0.strip() != s1.strip():
+                out.append((kern, line.strip()))
+    return out
+
+
 if __name__ == "__main__":
-    import os
-    import subprocess
     path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lanegcn-1_amd", "liblgcn.so")
     ks = kernels(path)
     names = subprocess.run(["c++filt"], input="\n".join(k["name"] for k in ks), capture_output=True, text=True).stdout.splitlines()
@@ -73,3 +112,7 @@ if __name__ == "__main__":
     for k, n in sorted(zip(ks, names), key=lambda t: (-t[0]["scratch"], t[1])):
         if k["scratch"] > 0 or "-a" in sys.argv:
             print("%-90s vgprs %3d spills %3d scratch %4d B lds %6d" % (n[:90], k["vgprs"], k["spills"], k["scratch"], k["lds"]))
+    rp = risky_packed(path)
+    print("packed fp32 instructions with a selected high half of source 1 (op_sel[1] = 1, other register): %d" % len(rp))
+    for kern, ins in rp[:20]:
+        print("  %s: %s" % (kern[:80], ins))

@@ -76,3 +76,29 @@ if what == "compare":
             nz = [c for c in cols if abs(w_[c]) > 1e-3][:6]
             print("  %s row %d: %d wrong channels (first %s); got/want at %s: %s; sum got %.5f want %.5f" %
                   (k, r, len(cols), cols[:12], nz, ["%.4f" % (g_[c] / w_[c]) for c in nz], g_.sum(), w_.sum()))
+
+if what == "compare":
+    # Which context row explains a wrong pair row?  m_p is recomputed in torch fp32 with V[c] for EVERY context row c;
+    # the best match says which w the kernel used for the V gather (the pair's own w, 0, another pair's ...).
+    import torch.nn.functional as F
+    k = "old/m0"
+    d = (out[k] - ref[k]).abs()
+    rows = (d > 1e-5).any(1).nonzero().flatten()
+    if len(rows):
+        hi, wi = ps.hi[:P].long().cpu(), ps.wi[:P].long().cpu()
+        ac, cc = ps.agt_ctrs.cpu(), ps.ctx_ctrs.cpu()
+        Uc, Vc = out["old/U0"], out["old/V0"]
+        cpu = lambda t: t.detach().float().cpu()
+        d0, d2, c0m = att0.dist[0], att0.dist[2], att0.ctx[0]
+        for r in rows[:12].tolist():
+            dd = ac[hi[r]] - cc[wi[r]]
+            e = F.relu(F.linear(dd, cpu(d0.weight), cpu(d0.bias)))
+            e = F.relu(F.group_norm(F.linear(e, cpu(d2.linear.weight))[None], 1, cpu(d2.norm.weight), cpu(d2.norm.bias), d2.norm.eps))[0]
+            t = F.linear(e, cpu(c0m.linear.weight)[:, :128]) + Uc[hi[r]]
+            cand = F.relu(F.group_norm(t[None] + Vc, 1, cpu(c0m.norm.weight), cpu(c0m.norm.bias), c0m.norm.eps))      # [S, 128]
+            err = (cand - out[k][r][None]).abs().max(1).values
+            best = int(err.argmin())
+            same_w = (wi == best).nonzero().flatten()
+            print("  row %d (tile %d, row in tile %d, lane %d): own w = %d (err %.2g), best w = %d (err %.2g); pairs with that w: %s; "
+                  "w of rows -64 / -8 / -2 / -1 / +1 / +64: %s" % (r, r // 64, r % 64, (r % 8) * 8, int(wi[r]), float(err[wi[r]]), best, float(err[best]),
+                  same_w[:6].tolist(), [int(wi[r + o]) if 0 <= r + o < P else None for o in (-64, -8, -2, -1, 1, 64)]))
