@@ -68,6 +68,25 @@ def _worker(rank, world, port, q):
         D.allreduce_mean_grads(two.parameters())
         assert torch.allclose(two[0].weight.grad, torch.full((4, 4), 2.0 * 1 / world))      # rank 0: sum over 2 rows of 1
         assert torch.allclose(two[1].weight.grad, torch.full((4, 4), 2.0 * 2 / world))      # rank 1: 2 rows of 2
+        # the persistent bucket: gradients are views of one buffer, same averages, in place, step after step
+        torch.manual_seed(0)
+        net2 = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.GroupNorm(1, 8), torch.nn.Linear(8, 3))
+        net2[2].weight.requires_grad_(rank >= 0)
+        bucket = D.GradBucket(net2.parameters())
+        assert bucket.flat.numel() == sum(p.numel() for p in net2.parameters())
+        for step in range(2):
+            bucket.zero()
+            net2(torch.full((4, 8), float(rank + 1 + step))).sum().backward()
+            assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, bucket.views))
+            local = [p.grad.clone() for p in net2.parameters()]
+            bucket.allreduce_mean()
+            every = [None] * world
+            dist.all_gather_object(every, local)
+            for i, p in enumerate(net2.parameters()):
+                assert torch.allclose(p.grad, sum(g[i] for g in every) / world, atol=1e-6)
+        net2.zero_grad(set_to_none=True)                  # something dropped the views: attach() brings them back
+        bucket.zero()
+        assert all(p.grad is v for p, v in zip(bucket.params, bucket.views)) and float(bucket.flat.abs().sum()) == 0.0
         D.barrier()
         q.put((rank, "ok"))
     except Exception as e:  # noqa: BLE001

@@ -120,6 +120,7 @@ def main(argv=None):
     epoch = round(float(config["epoch"]) * num_batches) / num_batches
     it, t0, metrics = 0, time.time(), dict()
     last_path, done = None, False
+    bucket = D.GradBucket(net.parameters())                        # persistent flat gradient buffer (p.grad = views of it)
     for ep in range(int(epoch + 0.5 / num_batches), config["num_epochs"]):
         for data in batches(dataset, collate_fn, config["batch_size"], rank, world, seed=0, epoch=ep):
             epoch += 1.0 / num_batches
@@ -127,9 +128,9 @@ def main(argv=None):
             loss_out = loss(out, data)
             post_out = post_process(out, data)
             post_process.append(metrics, loss_out, post_out)
-            opt.zero_grad()
-            loss_out["loss"].backward()
-            D.allreduce_mean_grads(net.parameters())              # Horovod DistributedOptimizer semantics
+            bucket.zero()                                          # the reference's opt.zero_grad(): one fill of the flat bucket
+            loss_out["loss"].backward()                            # accumulates into the bucket's views
+            bucket.allreduce_mean()                                # Horovod DistributedOptimizer semantics, one in-place all-reduce
             lr = opt.step(epoch)
             it += 1
             num_iters = int(np.round(epoch * num_batches))
