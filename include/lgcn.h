@@ -96,7 +96,8 @@ int lgcn_csr_build(const int64_t *const *u_host, const int64_t *const *v_host,
  *   rowptr   : [T+1] int32 output: rowptr[h] = first pair with hi >= h, i.e.
  *              the segments index_add_(0, hi, .) (:703) reduces over
  *   ws       : int32 workspace, lgcn_pairs_ws_elems(T, B) elements
- * If P would exceed cap the pairs beyond cap are dropped and *n_pairs = -P.
+ * If P would exceed cap the pairs beyond cap are dropped, *n_pairs = -P, and rowptr describes the pairs that were kept
+ * (every entry <= cap): consumers stay inside [cap, .] buffers; the caller sees the sign, grows cap and runs again.
  */
 int64_t lgcn_pairs_ws_elems(int64_t n_agt, int n_scenes);
 int lgcn_pairs_build(const float *agt_ctrs, const int32_t *agt_off,

@@ -237,9 +237,12 @@ __device__ __forceinline__ void pairs_rows_body(const float2 *agt, const int32_t
             s1 = s1 < s0 ? s0 : s1 > n_agt ? n_agt : s1;
             const bool advances = !legacy || rowptr[s1] - rowptr[s0] > 0;
             const int q2 = hi_base[n_scenes] + g - hi_base[sc];
-            if (advances) { if (hval >= 0 && hval <= n_agt) rowptr_q[hval] = (int)pos; }
-            else if (q2 >= 0 && q2 <= n_agt) rowptr_q[q2] = P;
-            if (g == 0) rowptr_q[n_agt] = P;
+            // a capacity below the true pair count (n_pairs comes back negative): the segment table describes the pairs
+            // that were kept, [0, cap) -- whatever walks it afterwards stays inside the caller's [cap, .] buffers
+            const int Pc = (int64_t)P > cap ? (int)cap : P;
+            if (advances) { if (hval >= 0 && hval <= n_agt) rowptr_q[hval] = pos > cap ? (int)cap : (int)pos; }
+            else if (q2 >= 0 && q2 <= n_agt) rowptr_q[q2] = Pc;
+            if (g == 0) rowptr_q[n_agt] = Pc;
         }
     }
     for (int s0 = c0; s0 < c1; s0 += 64) {

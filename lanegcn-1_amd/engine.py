@@ -186,6 +186,15 @@ class HotPathEngine:
         # the integer stage as lgcn_index_build (4 launches) instead of 12; False: the separate entry points
         self.fused_index = os.environ.get("LGCN_INDEX", "fused") == "fused"
         self._cnt_capture = None      # counter buffer of the forward being captured (capture(); it lives with the graph)
+        # Pair capacities (rows of hi / wi and of every [cap, 128] pair-row buffer of a forward).  "bound": sum_i t_i s_i,
+        # can never overflow (265 MB of pair rows per A2M layer at S2, untouched but reserved).  "tight" (default):
+        # 1.25 x the largest pair count this engine has seen per set, at least 4,096 (the bound until a count is known)
+        # -- learnt by capture() from its eager warm-up forwards (one host read each) and by forward_guarded() /
+        # Net.forward's host read; a forward whose count exceeds it comes back with a negative n_pairs (the kernels keep
+        # to the capacity), learn_pair_counts(out) says so and grows the capacity, the caller runs again; a captured
+        # graph has to be captured again.
+        self.pair_caps = os.environ.get("LGCN_PAIR_CAPS", "tight")
+        self._pair_seen = [0, 0, 0]
 
     def _counters(self, fb: FlatBatch) -> torch.Tensor:
         """Key counters of lgcn_index_build (zero before, zero after).  A captured forward owns a buffer of its own
@@ -223,6 +232,8 @@ class HotPathEngine:
         searches = ((fb.node_ctrs, fb.node_off, fb.actor_ctrs, fb.actor_off, cfg["actor2map_dist"], fb.cap_a2m),
                     (fb.actor_ctrs, fb.actor_off, fb.node_ctrs, fb.node_off, cfg["map2actor_dist"], fb.cap_a2m),
                     (fb.actor_ctrs, fb.actor_off, fb.actor_ctrs, fb.actor_off, cfg["actor2actor_dist"], fb.cap_a2a))
+        if self.pair_caps == "tight":      # nothing seen yet for a set: the bound (the first forward cannot overflow)
+            searches = tuple(s[:5] + (min(s[5], self._cap(i)) if self._pair_seen[i] > 0 else s[5],) for i, s in enumerate(searches))
         bufs = [ops.pairs_alloc(s[0].shape[0], fb.n_scenes, s[5], dev) for s in searches]   # on the main stream
         if side is not None:
             side.wait_stream(main)
@@ -286,10 +297,31 @@ class HotPathEngine:
         out["nonfinite"] = flag
         return out
 
+    def _cap(self, i: int) -> int:
+        """Tight capacity of pair set i (A2M, M2A, A2A): 1.25 x the largest count seen, at least 4,096, in 1,024s."""
+        want = max(4096, int(self._pair_seen[i] * 1.25) + 1)
+        return (want + 1023) // 1024 * 1024
+
+    def learn_pair_counts(self, out: Dict[str, torch.Tensor]) -> bool:
+        """Host side of the tight pair capacities: reads the forward's three pair counts (one device->host copy), keeps
+        the largest per set; True when a count exceeded its capacity (negative n_pairs: the forward's features are
+        those of a truncated pair set and must be recomputed with the grown capacity)."""
+        counts = torch.stack([c.view(()) for c in out["n_pairs"]]).tolist()
+        over = False
+        for i, c in enumerate(counts):
+            over = over or c < 0
+            self._pair_seen[i] = max(self._pair_seen[i], abs(int(c)))
+        return over
+
     def forward_guarded(self, fb: FlatBatch, actors: torch.Tensor, **kw) -> Dict[str, torch.Tensor]:
         """forward() + the host side of the range guard: reads the flag (one 4-byte device->host copy) and re-runs an
-        f16x2 forward that left fp16's range in bf16x3, or raises, as ops.set_guard() says."""
+        f16x2 forward that left fp16's range in bf16x3, or raises, as ops.set_guard() says.  With tight pair capacities
+        it also reads the pair counts and re-runs a forward that overflowed them."""
         out = self.forward(fb, actors, **kw)
+        if self.pair_caps == "tight" and not kw.get("mapnet_only") and self.learn_pair_counts(out):
+            out = self.forward(fb, actors, **kw)
+            if self.learn_pair_counts(out):
+                raise ops.L.LgcnError("pair capacity still exceeded after growing it")
         if ops.get_guard() == "off" or ops.get_mma() != "f16x2" or int(out["nonfinite"].item()) == 0:
             return out
         if ops.get_guard() == "raise":
@@ -357,8 +389,10 @@ class HotPathEngine:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):
-                self.forward(fb, actors, **fwd_kw)   # also fills the weight-pack caches outside the capture
+            for _ in range(max(warmup, 2 if self.pair_caps == "tight" else 0)):
+                o = self.forward(fb, actors, **fwd_kw)   # also fills the weight-pack caches outside the capture
+                if self.pair_caps == "tight" and not fwd_kw.get("mapnet_only"):
+                    self.learn_pair_counts(o)           # the captured buffers are sized for THIS batch's counts x 1.25
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with self.own_counters(fb) as cnt:
@@ -425,8 +459,9 @@ class FullNetEngine:
             reg = torch.einsum("amtk,akj->amtj", reg, rot) + orig.view(-1, 1, 1, 2)
         res = {"cls": cls, "reg": reg, "nonfinite": hot["nonfinite"]}
         ops.check_finite(hot["nonfinite"], reg.reshape(-1), cls.reshape(-1), bit=2)      # PredNet's row blocks too
-        if return_pairs:
-            res["n_pairs"] = hot["n_pairs"]     # device counts of the three pair sets (A2M, M2A, A2A)
+        # device counts of the three pair sets (A2M, M2A, A2A): Att.strict's check and the tight pair capacities
+        # (negative = capacity exceeded, HotPathEngine.learn_pair_counts); `return_pairs` is kept for callers of round 2
+        res["n_pairs"] = hot["n_pairs"]
         return res
 
     def capture(self, fb, actor_feats, rot, orig, sizes, warmup: int = 3, tune_convs: bool = True,
@@ -441,7 +476,9 @@ class FullNetEngine:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):
-                    self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
+                    o = self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
+                    if self.hot.pair_caps == "tight" and self.hot.learn_pair_counts(o):      # sized for this batch x 1.25
+                        self.forward(fb, actor_feats, rot, orig, sizes, **fwd_kw)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             with self.hot.own_counters(fb) as cnt:

@@ -980,8 +980,20 @@ class Net(nn.Module):
         if m["n_nodes"] == 0 or m["n_edges"][2 * ns - 2] == 0 or m["n_edges"][2 * ns - 1] == 0:
             raise KeyError("node_idcs")
         fb, out = self._replay_or_run(eng, hfb, feats, rot, orig, sizes)
-        # one device->host read for both host-side checks: the range guard's flag and the pair counts
-        host = torch.cat([out["nonfinite"].view(1)] + ([c.view(1) for c in out["n_pairs"]] if Att.strict else [])).tolist()
+        # one device->host read for the host-side checks: the range guard's flag and the three pair counts
+        host = torch.cat([out["nonfinite"].view(1)] + [c.view(1) for c in out["n_pairs"]]).tolist()
+        if eng.hot.pair_caps == "tight":
+            seen = eng.hot._pair_seen
+            over = any(int(c) < 0 for c in host[1:])
+            for i, c in enumerate(host[1:]):
+                seen[i] = max(seen[i], abs(int(c)))
+            if over:      # a pair set outgrew its (tight) capacity: the features are those of a truncated set -- grow, run again
+                self.__dict__.get("_graph_state", {}).update(sig=None, graph=None, last=None)
+                dev = fb.node_ctrs.device
+                out = eng.forward(fb, feats.to(dev), rot.to(dev), orig.to(dev), sizes)
+                host = torch.cat([out["nonfinite"].view(1)] + [c.view(1) for c in out["n_pairs"]]).tolist()
+                if any(int(c) < 0 for c in host[1:]):
+                    raise L.LgcnError("pair capacity still exceeded after growing it")
         if ops.get_guard() != "off" and ops.get_mma() == "f16x2" and host[0] != 0:
             # an operand left fp16's range: the forward comes back with NaN rows; policy = re-run in bf16x3 or raise
             if ops.get_guard() == "raise":
@@ -992,7 +1004,7 @@ class Net(nn.Module):
             # the re-run has fp32's exponent range in every stage (ActorNet takes the MIOpen path outside f16x2, see
             # ActorNet._hip_ok): non-finite values that survive it were in the inputs or the weights, and are returned as
             # they are -- what the reference does with them
-            host = [0] + (torch.stack(out["n_pairs"]).flatten().tolist() if Att.strict else [])
+            host = [0] + torch.stack(out["n_pairs"]).flatten().tolist()
         if Att.strict and any(int(c) == 0 for c in host[1:]):
             raise RuntimeError("torch.cat(): expected a non-empty list of Tensors")
         # per-scene views in two calls (a Python slice per scene and tensor costs ~2 us each: 0.13 ms at batch 32)

@@ -409,6 +409,63 @@ def test_engine_matches_modules_and_graph_replay(hip, ref_state_names):
         assert np.array_equal(gout["nodes"].cpu().numpy(), want["m2m"]) and np.array_equal(gout["actors"].cpu().numpy(), want["a2a"])
 
 
+def test_tight_pair_capacities_overflow_is_flagged_safe_and_regrown(hip, ref_state_names):
+    """Pair buffers sized below sum_i t_i s_i (engine default: 1.25 x the counts it has seen): a forward whose pair sets
+    outgrow them reports NEGATIVE counts, its segment tables stay inside the capacity (nothing reads or writes past the
+    [cap, .] buffers), learn_pair_counts() grows the capacities and the next forward equals the one with the bound
+    capacities bit for bit; forward_guarded does the whole loop; lgcn_pairs_build alone: first cap pairs, clamped rowptr."""
+    M, ops = hip
+    from lanegcn_amd import data as gen
+    from lanegcn_amd.engine import HotPathEngine, collate_flat
+    sd = O.seeded_state(ref_state_names, 11)
+    mods = make_modules(M, sd)
+    scenes_np = gen.synth_batch("S2", seed=3, n_scenes=16)
+    fb = collate_flat(scenes_np)
+    actors = torch.from_numpy(np.random.default_rng(2).normal(0, 1, (fb.n_actors, 128)).astype(np.float32)).relu().cuda()
+    args = (mods["map_net"], mods["a2m"], mods["m2m"], mods["m2a"], mods["a2a"])
+    bound = HotPathEngine(*args)
+    bound.pair_caps = "bound"
+    want = bound.forward(fb, actors)
+    counts = [int(c) for c in torch.stack(want["n_pairs"]).flatten().tolist()]
+    assert min(counts) > 4096
+    eng = HotPathEngine(*args)
+    assert eng.pair_caps == "tight"
+    first = eng.forward(fb, actors)                       # nothing seen yet: the bound, cannot overflow
+    assert not eng.learn_pair_counts(first) and eng._pair_seen == counts
+    assert torch.equal(first["nodes"], want["nodes"]) and torch.equal(first["actors"], want["actors"])
+    tight = eng.forward(fb, actors)                       # 1.25 x the counts
+    assert torch.equal(tight["nodes"], want["nodes"]) and torch.equal(tight["actors"], want["actors"])
+    assert [int(c) for c in torch.stack(tight["n_pairs"]).flatten().tolist()] == counts
+    # a batch with more pairs than the engine has seen: pretend it has only seen a tenth
+    eng._pair_seen = [max(c // 10, 1) for c in counts]
+    caps = [eng._cap(i) for i in range(3)]
+    assert all(cap < c for cap, c in zip(caps, counts))
+    over = eng.forward(fb, actors)
+    assert [int(c) for c in torch.stack(over["n_pairs"]).flatten().tolist()] == [-c for c in counts]
+    assert torch.isfinite(over["nodes"]).all() and torch.isfinite(over["actors"]).all()
+    assert eng.learn_pair_counts(over) and eng._pair_seen == counts
+    again = eng.forward(fb, actors)
+    assert torch.equal(again["nodes"], want["nodes"]) and torch.equal(again["actors"], want["actors"])
+    eng._pair_seen = [max(c // 10, 1) for c in counts]
+    auto = eng.forward_guarded(fb, actors)
+    assert torch.equal(auto["nodes"], want["nodes"]) and torch.equal(auto["actors"], want["actors"])
+    # a captured forward is sized from its warm-up forwards
+    eng2 = HotPathEngine(*args)
+    graph, gout = eng2.capture(fb, actors)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert eng2._pair_seen == counts
+    assert torch.equal(gout["nodes"], want["nodes"]) and torch.equal(gout["actors"], want["actors"])
+    # the search alone
+    full = ops.pairs_build(fb.node_ctrs, fb.node_off, fb.actor_ctrs, fb.actor_off, M.config["actor2map_dist"], fb.cap_a2m, True)
+    P = full.count()
+    cap = P // 3
+    cut = ops.pairs_build(fb.node_ctrs, fb.node_off, fb.actor_ctrs, fb.actor_off, M.config["actor2map_dist"], cap, True)
+    assert int(cut.n_pairs.item()) == -P and cut.hi.numel() == cap
+    assert torch.equal(cut.hi, full.hi[:cap]) and torch.equal(cut.wi, full.wi[:cap])
+    assert torch.equal(cut.rowptr, full.rowptr.clamp(max=cap))
+
+
 def test_captured_forwards_keep_their_inputs_and_counters(hip, ref_state_names):
     """A hipGraph holds addresses, not references: capture() must keep the FlatBatch, the actor tensor and the index
     counters of a captured forward alive.  Two lanes are captured, every outside reference to their inputs is dropped,
