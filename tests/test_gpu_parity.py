@@ -429,7 +429,7 @@ def test_tight_pair_capacities_overflow_is_flagged_safe_and_regrown(hip, ref_sta
     counts = [int(c) for c in torch.stack(want["n_pairs"]).flatten().tolist()]
     assert min(counts) > 4096
     eng = HotPathEngine(*args)
-    assert eng.pair_caps == "tight"
+    eng.pair_caps = "tight"                                # the default unless LGCN_PAIR_CAPS says otherwise
     first = eng.forward(fb, actors)                       # nothing seen yet: the bound, cannot overflow
     assert not eng.learn_pair_counts(first) and eng._pair_seen == counts
     assert torch.equal(first["nodes"], want["nodes"]) and torch.equal(first["actors"], want["actors"])
@@ -451,6 +451,7 @@ def test_tight_pair_capacities_overflow_is_flagged_safe_and_regrown(hip, ref_sta
     assert torch.equal(auto["nodes"], want["nodes"]) and torch.equal(auto["actors"], want["actors"])
     # a captured forward is sized from its warm-up forwards
     eng2 = HotPathEngine(*args)
+    eng2.pair_caps = "tight"
     graph, gout = eng2.capture(fb, actors)
     graph.replay()
     torch.cuda.synchronize()
