@@ -145,6 +145,86 @@ __global__ __launch_bounds__(256) void k_lc_plan(const LcPlanParams p) {
             keys[j] = -1;
             if (degs[j] == 1) keys[j] = p.col[e0s[j]];
         }
+        // ---- one wave per row block (M <= 64: the short and the shared shape): every id in ONE pass instead of a chain of
+        // ~5 barriers per unit.  The sequential rule below -- units in order, inside a unit the rows in order, a source's
+        // id goes to the first (unit, row) that names it, rows with several edges always get a virtual row -- is "rank the
+        // winners by (unit, row)": every (unit, row) with one source enters the hash, the lowest code of a key owns it,
+        // and with one wave the ranks are ballots and a running total.  If the whole range fits one item (always, for
+        // the shapes whose cap is the largest count the lane graphs produce) the plan is written from here; otherwise
+        // the hash is cleared again and the sequential path splits the range.
+        if (nt == 64) {
+            int slot[kLcUnits], myid[kLcUnits], first[kLcUnits];
+            // the first probe of all 15 units is issued together (independent LDS atomics: one round trip, not 15)
+#pragma unroll
+            for (int j = 0; j < kLcUnits; ++j) {
+                const int u = u_begin + j;
+                if (u == 0 && u < u_end) { degs[j] = row_ok ? 1 : 0; keys[j] = (int)n; }      // ctr: the row itself
+                slot[j] = -1;
+                first[j] = -1;
+                if (u < u_end && degs[j] == 1) {
+                    slot[j] = (int)(((unsigned)keys[j] * 2654435761u) >> 22);
+                    first[j] = atomicCAS(&hkey[slot[j]], -1, keys[j]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < kLcUnits; ++j) {
+                if (slot[j] >= 0) {
+                    unsigned h = (unsigned)slot[j];
+                    int k0 = first[j];
+                    while (k0 != -1 && k0 != keys[j]) {      // collision: linear probing
+                        h = (h + 1) & (kLcHash - 1);
+                        k0 = atomicCAS(&hkey[h], -1, keys[j]);
+                    }
+                    slot[j] = (int)h;
+                    atomicMin(&hrow[h], (j << 8) | tid);
+                }
+            }
+            lds_barrier();
+            int total = 0, n_live = 0;
+            int masks[kLcUnits];
+#pragma unroll
+            for (int j = 0; j < kLcUnits; ++j) {
+                const bool in_range = u_begin + j < u_end;
+                const bool winner = in_range && (degs[j] >= 2 || (degs[j] == 1 && hrow[slot[j]] == ((j << 8) | tid)));
+                const unsigned long long bal = __ballot(winner);
+                myid[j] = winner ? total + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+                total += __popcll(bal);
+                if (winner && degs[j] == 1) hval[slot[j]] = myid[j];
+                const unsigned long long bd = __ballot(in_range && degs[j] > 0);
+                int wm = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if ((bd >> (16 * q)) & 0xffffull) wm |= 1 << q;
+                masks[j] = wm;
+                if (in_range && wm != 0) ++n_live;
+            }
+            if (total <= p.cap) {
+                lds_barrier();                             // the owners' ids are in hval
+                int k = 0;
+#pragma unroll
+                for (int j = 0; j < kLcUnits; ++j) {
+                    const int u = u_begin + j;
+                    if (u >= u_end) continue;
+                    if (tid == 0) maskp[(int64_t)b * kLcUnits + u] = masks[j];
+                    if (masks[j] == 0) continue;
+                    if (tid == 0) s_ul[k] = u;
+                    ++k;
+                    if (myid[j] >= 0)
+                        srcp[((int64_t)b * kLcUnits + u_begin) * p.cap + myid[j]] =
+                            degs[j] == 1 ? make_int2(keys[j], 0) : make_int2(e0s[j], degs[j]);
+                    int loc = 0xffff;
+                    if (degs[j] == 1) loc = hval[slot[j]];
+                    else if (degs[j] >= 2) loc = myid[j];
+                    if (tid < p.M) locp[((int64_t)b * kLcUnits + u) * 256 + (tid & 15) * 16 + (tid >> 4)] = (uint16_t)loc;
+                }
+                lds_barrier();                             // s_ul
+                finalize(u_begin, n_live, total, u_end - u_begin);
+                return;
+            }
+            if (u_begin == 0) { degs[0] = 0; keys[0] = -1; }      // the loop below forms the ctr unit itself
+            clear();
+            lds_barrier();
+        }
 #pragma unroll
         for (int j = 0; j < kLcUnits; ++j) {
             s_pre[(3 * j) * 256 + tid] = e0s[j];
