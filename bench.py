@@ -311,12 +311,16 @@ def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup, trac
     # the lane streams are created FIRST: torch hands out its pool streams in order and ROCm maps consecutive HIP
     # streams to consecutive hardware queues (4 by default), so these S streams get S distinct queues
     lane_streams = lanes_streams(S)
-    lanes = []
+    lanes, pools = [], []
     for j in range(S):
         sc = scenes if j == 0 else gen.synth_batch(args.workload, seed=100 + rank + 1000 * j, n_scenes=args.scenes)
         fbj = fb if j == 0 else collate_flat(sc, dev)
         aj = actors if j == 0 else torch.randn(fbj.n_actors, C, device=dev).relu()
+        torch.cuda.empty_cache()
+        r0 = torch.cuda.memory_reserved(dev)
         gj, oj = eng_multi.capture(fbj, aj, mapnet_only=args.mapnet_only)
+        torch.cuda.empty_cache()           # what stays reserved is the graph's private pool (every buffer of the forward)
+        pools.append((torch.cuda.memory_reserved(dev) - r0) / 2**20)
         lanes.append((lane_streams[j], gj, oj, fbj, aj))
     # one-time costs of a graph belong to its capture, not to the first timed replays: every lane's graph is replayed a
     # few times on the stream it will run on (executable-graph upload, first-touch of its private pool)
@@ -337,6 +341,7 @@ def run_mode(args, mma, mods, scenes, fb, actors, dev, rank, steps, warmup, trac
 
     elapsed = time_steps(step, steps, warmup, D.barrier, dev)
     res.update(ms_per_step=elapsed / steps * 1e3, elapsed=elapsed, streams=S)
+    res["graph_pool_MB_per_lane"] = [round(x, 1) for x in pools]
     if trace:
         # the same K steps once more, untimed on the host, with a HIP event behind every replay: when each step finished
         # on the device, measured from an event recorded on the idle GPU (attributes the fill / drain of the S lanes)
@@ -613,6 +618,8 @@ def main():
         }
         if stages_tab is not None:
             line["stages"] = stages_tab
+        if "graph_pool_MB_per_lane" in head:      # device memory a captured forward keeps (its private pool), per lane
+            line["graph_pool_MB_per_lane"] = head["graph_pool_MB_per_lane"]
         if "steady_ms_per_step" in head:
             line["value_steady"] = args.gpus * n_scenes / (head["steady_ms_per_step"] * 1e-3)
             line["steady_ms_per_step"] = head["steady_ms_per_step"]
