@@ -14,12 +14,20 @@ constexpr int kScanThreads = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanThreads * kScanItems;
 
-__device__ __forceinline__ int wave_inclusive_scan(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+// Inclusive scan over the 64 lanes at VALU speed: Hillis-Steele inside every row of 16 lanes (DPP row_shr 1, 2, 4, 8: a lane
+// without a source lane adds 0), then the last lane of row 0 / 2 into rows 1 / 3 (row_bcast:15) and lane 31 into rows 2
+// and 3 (row_bcast:31).  (__shfl_up is ds_bpermute: an LDS round trip per step.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_add_from(int v) {
+    return v + __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ int wave_inclusive_scan(int v, int /*lane*/) {
+    v = dpp_add_from<0x111, 0xf>(v);
+    v = dpp_add_from<0x112, 0xf>(v);
+    v = dpp_add_from<0x114, 0xf>(v);
+    v = dpp_add_from<0x118, 0xf>(v);
+    v = dpp_add_from<0x142, 0xa>(v);
+    v = dpp_add_from<0x143, 0xc>(v);
     return v;
 }
 
@@ -31,10 +39,11 @@ __device__ __forceinline__ int block_exclusive_scan(int v, int *total, int *lds 
     const int inc = wave_inclusive_scan(v, lane);
     if (lane == 63) lds[w] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int i = 0; i < NT / 64; ++i) { int t = lds[i]; lds[i] = run; run += t; }
-        lds[NT / 64] = run;
+    if (w == 0) {      // the wave totals are scanned by the first wave (it was a serial loop of one thread: 16 LDS round trips)
+        const int t = lane < NT / 64 ? lds[lane] : 0;
+        const int run = wave_inclusive_scan(t, lane);
+        if (lane < NT / 64) lds[lane] = run - t;
+        if (lane == NT / 64 - 1) lds[NT / 64] = run;
     }
     __syncthreads();
     const int base = lds[w];
