@@ -1097,6 +1097,56 @@ def test_net_forward_graph_cache(golden, ref_state_names, hip):
         assert not torch.equal(o5["cls"][0], keep[1][0])
 
 
+def test_net_forward_graph_replay_with_other_content(golden, ref_state_names, hip):
+    """The captured whole-Net graph replayed on a batch of the SAME signature (shapes, per-scene sizes) but other content --
+    actor tracks and centres moved, so the pair sets change too: equal to the eager forward of that batch; results handed
+    out earlier stay what they were (the caller owns them).  (Pair sets that outgrow a captured graph's capacities:
+    test_tight_pair_capacities_overflow_is_flagged_safe_and_regrown, on the engine.)"""
+    M, _ = hip
+    import copy
+    from lanegcn_amd import data as gen
+    net = M.Net(M.config)
+    net.load_state_dict(O.seeded_state(ref_state_names, int(golden["seed"])), strict=True)
+    net = net.cuda().eval()
+    scenes = load_scenes(golden)
+    rng = np.random.default_rng(9)
+
+    def moved(scale, one_spot=False):
+        out = copy.deepcopy(scenes)
+        for sc in out:
+            f, c = np.asarray(sc["feats"], np.float32), np.asarray(sc["ctrs"], np.float32)
+            sc["feats"] = (f * 0.9).astype(np.float32)
+            c = c + rng.normal(0, scale, c.shape).astype(np.float32)
+            if one_spot:          # every actor of a scene on the first lane node: far more pairs of every kind
+                c = c * 0 + np.asarray(sc["graph"]["ctrs"], np.float32)[:1]
+            sc["ctrs"] = c.astype(np.float32)
+        return out
+
+    a, b, far = gen.collate_fn(scenes), gen.collate_fn(moved(0.3)), gen.collate_fn(moved(0.0, one_spot=True))
+    close = lambda x, y: torch.allclose(x, y, rtol=1e-5, atol=2e-4)
+    with torch.no_grad():
+        M.Net.graph_cache = False
+        try:
+            want_b, want_far = net(b), net(far)
+        finally:
+            M.Net.graph_cache = True
+        net.__dict__.pop("_graph_state", None)
+        net.__dict__["_engine"].hot._pair_seen = [0, 0, 0]          # forget the counts the eager runs have taught the engine
+        first = net(a)
+        held = net(a)                                    # captured here
+        assert net.__dict__["_graph_state"]["graph"] is not None
+        keep = [t.clone() for t in held["reg"]]
+        got_b = net(b)                                   # same signature, other content: replay
+        assert net.__dict__["_graph_state"]["graph"] is not None
+        for i in range(len(scenes)):
+            assert close(got_b["reg"][i], want_b["reg"][i]) and close(got_b["cls"][i], want_b["cls"][i]), i
+            assert torch.equal(held["reg"][i], keep[i]), "a result handed out earlier was overwritten by the replay"
+            assert close(first["reg"][i], held["reg"][i])
+        got_far = net(far)                               # every actor of a scene on one spot: other pair sets again
+        for i in range(len(scenes)):
+            assert close(got_far["reg"][i], want_far["reg"][i]) and close(got_far["cls"][i], want_far["cls"][i]), i
+
+
 # ------------------------------------------------------------------ round 3: folded row-block launches of the Att blocks
 def test_chained_outputs_and_multi_launch_equal_separate_launches(hip):
     """lgcn_agg_mlp's chained outputs (ch_*: the NEXT Att layer's U / V computed from a row block's output rows before
