@@ -72,6 +72,17 @@ def test_no_shipped_kernel_holds_the_miscomputed_packed_form():
     import kernel_resources as kr
     if not os.path.exists(kr.OBJDUMP):
         pytest.skip("llvm-objdump not found")
+    # the line classifier on the forms tools/micro/pk_opsel.hip measured (llvm-objdump's layout, with and without its comment)
+    bad = ["\tv_pk_mul_f32 v[22:23], v[20:21], v[50:51] op_sel:[0,1] op_sel_hi:[1,0]// 000000004368: D3B1 0816",
+           "  v_pk_add_f32 v[74:75], v[74:75], v[78:79] op_sel:[0,1] op_sel_hi:[1,0]",
+           "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]",
+           "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,0,1]"]
+    good = ["\tv_pk_add_f32 v[124:125], v[120:121], v[120:121] op_sel:[0,1] op_sel_hi:[1,0]",      # one pair's horizontal add
+            "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0]", "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5]",
+            "\tv_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0] op_sel_hi:[0,1]",
+            "\tv_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[1,0,0]", "\tv_pk_mov_b32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]",
+            "\tv_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[8:11], v[0:3]"]
+    assert all(kr._risky_line(l) for l in bad) and not any(kr._risky_line(l) for l in good)
     found = kr.risky_packed(os.path.join(ROOT, "lanegcn-1_amd", "liblgcn.so"))
     assert not found, found[:5]
     # the detector itself: the compare + select diagnostic build (SLP on) is where the form was first seen
