@@ -1189,6 +1189,19 @@ def test_chained_outputs_and_multi_launch_equal_separate_launches(hip):
                 assert torch.equal(o, want)
 
 
+@pytest.mark.parametrize("rb", [1, 2, 3, 4])
+def test_row_blocks_at_every_tile_height(hip, rb):
+    """lgcn_agg_mlp in its Linear / Att roles (plain, two stages + residual, RANGE / RANGE16 segment sums, an Att tail with
+    chained U and V, A2M.meta's rank-4 update with a chained U, several problems in one launch) at a forced tile height of
+    16 rb rows: bit for bit what the library's own pick gives (pick_rb takes 48-row tiles for these roles at some batch
+    sizes, e.g. 54 S2 scenes; the fixtures and S2 itself only ever run 16- and 32-row tiles)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import check_tile_rb
+    assert check_tile_rb.run(rb, verbose=False) == []
+
+
 def test_folded_att_blocks_equal_per_layer_launches(gcase, hip):
     """lanegcn.att_block (a layer's tail emits the next layer's U / V, V rows up front, A2M.meta chained into the first
     U, M2A's last tail feeding A2A) against Att.run layer by layer: bit for bit, on the reference's fixture scenes
